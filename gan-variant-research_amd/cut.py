@@ -1,0 +1,564 @@
+"""Host-side mirror of the reference's GAN_Variant1 (CUT) trainer on the MI355X kernels.
+
+Same names, argument meaning and state_dict keys as the reference (paths relative to its root):
+ResNetGenerator / MultiscaleDiscriminator (models/generator_resnet_attn.py:74-235, models/discriminator_patchgan.py:75-128),
+DiffAugment (training/diffaugment.py:76-106), get_optimizer (training/sched_optim.py:5-27), EMA (utils/io_ckpt.py:9-53),
+AMPContext (utils/amp_utils.py:5-41), build_models / train_step (training/train_cutpp.py:88-124, 206-331).
+
+The modules are parameter containers (default PyTorch init on the CPU generator, reference key names); all
+arithmetic runs in libmi355x_gan.so through CutTrainer, which owns the buffers and the replayable step programs.
+"""
+from __future__ import annotations
+
+import math
+import random
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ._lib import ACT_NONE, BF16, F32, HALO_ZERO
+from .nets import DiscriminatorNet, GeneratorNet
+from .runtime import ADAM_CHUNK, Ctx, HipOps, Program, View, cpad
+
+NCE_LAYERS_DEFAULT = (0, 4, 8, 12, 16)
+
+
+def set_seed(seed: int):
+    """utils/seed_dist.py:7-12."""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers with the reference's module tree (so state_dict keys and init order match)
+# ------------------------------------------------------------------------------------------------
+def _slot(n):
+    return [nn.Identity() for _ in range(n)]
+
+
+class _ResBlockParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        seq = _slot(7)
+        seq[1], seq[5] = nn.Conv2d(c, c, 3), nn.Conv2d(c, c, 3)
+        self.conv_block = nn.Sequential(*seq)
+
+
+class ResNetGenerator(nn.Module):
+    """Signature of models/generator_resnet_attn.py:86-103 (the attention/style kwargs are accepted and ignored there too)."""
+
+    def __init__(self, input_nc=3, output_nc=3, ngf=64, n_blocks=9, n_downsampling=2, padding_type="reflect", norm="instance",
+                 activation="relu", use_attention=True, attn_layers=(3, 7), use_channel_attn=True, channel_attn_layers=(5,),
+                 use_style_dropout=True, alpha_min=0.4, alpha_max=0.9):
+        super().__init__()
+        if (padding_type, norm, activation, n_downsampling) != ("reflect", "instance", "relu", 2):
+            raise NotImplementedError("MI355X path implements the baseline config: reflect padding, instance norm, ReLU, 2 downsamplings")
+        self.input_nc, self.output_nc, self.ngf, self.n_blocks = input_nc, output_nc, ngf, n_blocks
+        s = _slot(4); s[1] = nn.Conv2d(input_nc, ngf, 7)
+        self.initial = nn.Sequential(*s)
+        s = _slot(6); s[0], s[3] = nn.Conv2d(ngf, 2 * ngf, 3, stride=2, padding=1), nn.Conv2d(2 * ngf, 4 * ngf, 3, stride=2, padding=1)
+        self.downsample = nn.Sequential(*s)
+        self.res_blocks = nn.ModuleList([_ResBlockParams(4 * ngf) for _ in range(n_blocks)])
+        s = _slot(6)
+        s[0] = nn.ConvTranspose2d(4 * ngf, 2 * ngf, 3, stride=2, padding=1, output_padding=1)
+        s[3] = nn.ConvTranspose2d(2 * ngf, ngf, 3, stride=2, padding=1, output_padding=1)
+        self.upsample = nn.Sequential(*s)
+        s = _slot(3); s[1] = nn.Conv2d(ngf, output_nc, 7)
+        self.output = nn.Sequential(*s)
+        self._runner = None
+
+    def _run(self, x, layer_ids=None):
+        if self._runner is None or self._runner.key != (tuple(x.shape), x.device):
+            self._runner = _InferenceRunner(self, x)
+        return self._runner(x, layer_ids)
+
+    @torch.no_grad()
+    def forward(self, x):
+        """(B,3,H,W) fp32 in [-1,1] -> (B,3,H,W) fp32; inference on the HIP kernels (training goes through CutTrainer)."""
+        return self._run(x)
+
+    @torch.no_grad()
+    def get_feature_layers(self, x, layer_ids=None):
+        return self._run(x, list(NCE_LAYERS_DEFAULT) if layer_ids is None else list(layer_ids))
+
+
+class _PatchGANParams(nn.Module):
+    def __init__(self, input_nc, ndf, n_layers):
+        super().__init__()
+        chans = [input_nc, ndf] + [ndf * min(2**n, 8) for n in range(1, n_layers)] + [ndf * min(2**n_layers, 8), 1]
+        seq = []
+        for i in range(len(chans) - 1):
+            seq.append(nn.Conv2d(chans[i], chans[i + 1], 4, stride=2 if i < n_layers else 1, padding=1))
+            if i < len(chans) - 2:
+                seq.append(nn.Identity())
+        self.model = nn.Sequential(*seq)
+
+
+class MultiscaleDiscriminator(nn.Module):
+    """Signature of models/discriminator_patchgan.py:81-88; the baseline config is one scale, no spectral norm."""
+
+    def __init__(self, input_nc=3, ndf=64, n_layers=3, num_scales=3, use_spectral_norm=True):
+        super().__init__()
+        if num_scales != 1 or use_spectral_norm:
+            raise NotImplementedError("MI355X path implements the baseline config: num_scales=1, use_spectral_norm=False")
+        self.input_nc, self.ndf, self.n_layers, self.num_scales = input_nc, ndf, n_layers, num_scales
+        self.discriminators = nn.ModuleList([_PatchGANParams(input_nc, ndf, n_layers)])
+
+
+def build_models(config, device):
+    """training/train_cutpp.py:88-124: construction on the CPU generator, then .to(device)."""
+    g, d = config["model"]["generator"], config["model"]["discriminator"]
+    gen = ResNetGenerator(3, 3, g["ngf"], g["n_blocks"], g["n_downsampling"], g["padding_type"], g["norm"], g["activation"]).to(device)
+    disc = MultiscaleDiscriminator(3, d["ndf"], d["n_layers"], d["num_scales"], d.get("use_spectral_norm", True)).to(device)
+    return gen, disc
+
+
+class DiffAugment:
+    """training/diffaugment.py:76-106.  Holds the policy; the draws are made by CutTrainer (or injected for parity)."""
+
+    def __init__(self, policy: Optional[Sequence[str]] = None):
+        self.policy = list(policy) if policy is not None else ["color", "translation", "cutout_light"]
+
+    def sample(self, B, H, W, generator=None) -> Dict[str, torch.Tensor]:
+        """Per-sample draws in the reference's order and shapes (diffaugment.py:8,15,22,29-30,47-48), on the CPU generator."""
+        d = {}
+        for pol in self.policy:
+            if pol == "color":
+                for k in ("brightness", "saturation", "contrast"):
+                    d[k] = torch.rand(B, 1, 1, 1, generator=generator)
+            elif pol == "translation":
+                sx, sy = int(H * 0.125 + 0.5), int(W * 0.125 + 0.5)
+                d["tx"] = torch.randint(-sx, sx + 1, size=[B, 1, 1], generator=generator)
+                d["ty"] = torch.randint(-sy, sy + 1, size=[B, 1, 1], generator=generator)
+            elif pol in ("cutout", "cutout_light"):
+                ratio = 0.5 if pol == "cutout" else 0.2
+                ch, cw = int(H * ratio + 0.5), int(W * ratio + 0.5)
+                d["cut_h"], d["cut_w"] = torch.tensor(ch), torch.tensor(cw)
+                d["cx"] = torch.randint(0, H + (1 - ch % 2), size=[B, 1, 1], generator=generator)
+                d["cy"] = torch.randint(0, W + (1 - cw % 2), size=[B, 1, 1], generator=generator)
+        return d
+
+    @staticmethod
+    def to_params(d: Dict[str, torch.Tensor], B, H, W) -> torch.Tensor:
+        """Draws -> the [B][12] fp32 table of gan_diffaug_*: brightness add, saturation and contrast factors, translation,
+        inclusive cutout window (rows/cols are clamped exactly as diffaugment.py:55-58 does)."""
+        p = torch.zeros(B, 12, dtype=torch.float32)
+        p[:, 1] = 1.0
+        p[:, 2] = 1.0
+        p[:, 5], p[:, 6], p[:, 7], p[:, 8] = 1, 0, 1, 0   # empty window
+        if "brightness" in d:
+            p[:, 0] = d["brightness"].reshape(B).float() - 0.5
+            p[:, 1] = d["saturation"].reshape(B).float() * 2
+            p[:, 2] = d["contrast"].reshape(B).float() + 0.5
+        if "tx" in d:
+            p[:, 3], p[:, 4] = d["tx"].reshape(B).float(), d["ty"].reshape(B).float()
+        if "cx" in d:
+            ch, cw = int(d["cut_h"]), int(d["cut_w"])
+            cx, cy = d["cx"].reshape(B), d["cy"].reshape(B)
+            p[:, 5] = (cx - ch // 2).clamp(0, H - 1).float()
+            p[:, 6] = (cx + ch - 1 - ch // 2).clamp(0, H - 1).float()
+            p[:, 7] = (cy - cw // 2).clamp(0, W - 1).float()
+            p[:, 8] = (cy + cw - 1 - cw // 2).clamp(0, W - 1).float()
+        return p
+
+
+class AMPContext:
+    """utils/amp_utils.py:5-41.  On the MI355X path "amp" selects bf16 operands with fp32 accumulation; there is no
+    GradScaler (bf16 has fp32's exponent range), so scale == 1 and found_inf never skips a step."""
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = enabled
+
+    @property
+    def dtype(self):
+        return BF16 if self.enabled else F32
+
+
+class FusedAdam:
+    """get_optimizer's torch.optim.Adam (sched_optim.py:5-27) over a flat parameter block, fused with clip_grad_norm_
+    and EMA.update (amp_utils.py:29-41, io_ckpt.py:23-29) in one multi-tensor launch."""
+
+    def __init__(self, ctx: Ctx, names: List[str], shapes: List[torch.Size], init: Dict[str, torch.Tensor], lr=2e-4, betas=(0.5, 0.999),
+                 eps=1e-8, weight_decay=0.0, ema_decay: Optional[float] = None):
+        if weight_decay != 0.0:
+            raise NotImplementedError("weight_decay != 0 is not used by the reference configs")
+        self.ctx, self.names, self.lr, self.betas, self.eps, self.ema_decay = ctx, names, lr, betas, eps, ema_decay
+        sizes = [int(np.prod(s)) for s in shapes]
+        self.offsets = np.concatenate([[0], np.cumsum([(n + 3) // 4 * 4 for n in sizes])]).astype(np.int64)  # 16-byte aligned slices
+        total = int(self.offsets[-1])
+        dev = ctx.device
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self.flat_ema = torch.zeros_like(self.flat_p) if ema_decay is not None else None
+        self.steps = torch.zeros(len(names), dtype=torch.int32, device=dev)
+        self.params, self.grads, self.shadow = {}, {}, {}
+        for i, (n, shp, sz) in enumerate(zip(names, shapes, sizes)):
+            o = int(self.offsets[i])
+            self.params[n] = self.flat_p[o:o + sz].view(shp)
+            self.grads[n] = self.flat_g[o:o + sz].view(shp)
+            self.params[n].copy_(init[n])
+            if self.flat_ema is not None:
+                self.shadow[n] = self.flat_ema[o:o + sz].view(shp)
+                self.shadow[n].copy_(init[n])
+        self.sizes = sizes
+        ct, co = [], []
+        for i, sz in enumerate(sizes):
+            for off in range(0, sz, ADAM_CHUNK):
+                ct.append(i)
+                co.append(off)
+        self.nchunks = len(ct)
+        self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=dev)
+        self.chunk_off = torch.tensor(co, dtype=torch.int64, device=dev)
+        self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.ws = torch.zeros(self.nchunks + 16, dtype=torch.float32, device=dev)
+        self._tables = {}
+
+    def table(self, skip: Sequence[str] = ()) -> torch.Tensor:
+        key = tuple(sorted(skip))
+        if key not in self._tables:
+            ents = []
+            for i, n in enumerate(self.names):
+                o, sz = int(self.offsets[i]), self.sizes[i]
+                ents.append({"p": self.flat_p[o:o + sz], "g": None if n in skip else self.flat_g[o:o + sz], "m": self.flat_m[o:o + sz],
+                             "v": self.flat_v[o:o + sz], "ema": self.flat_ema[o:o + sz] if self.flat_ema is not None else None,
+                             "step": self.steps[i:i + 1]})
+            self._tables[key] = self.ctx.ops.make_adam_table(ents)
+        return self._tables[key]
+
+    def step_op(self, max_norm: Optional[float], grad_scale: float = 1.0, skip: Sequence[str] = ()):
+        return self.ctx.ops.adam_step(self.table(skip), len(self.names), self.chunk_tensor, self.chunk_off, self.nchunks, self.lr,
+                                      self.betas[0], self.betas[1], self.eps, max_norm if max_norm is not None else 0.0, grad_scale,
+                                      self.ema_decay if self.ema_decay is not None else 0.0, self.norm_out, self.ws)
+
+
+def get_optimizer_config(opt_config: dict) -> dict:
+    """sched_optim.py:16-18 defaults."""
+    return {"lr": opt_config.get("lr", 2e-4), "betas": tuple(opt_config.get("betas", [0.5, 0.999])),
+            "weight_decay": opt_config.get("weight_decay", 0.0)}
+
+
+def identity_weight_at(step: int, config: dict) -> float:
+    lw, ws = config["loss_weights"], config.get("warmup_steps", 20000)   # train_cutpp.py:224-228
+    if step < ws:
+        return lw["identity_warm"] + (lw["identity_final"] - lw["identity_warm"]) * (step / ws)
+    return lw["identity_final"]
+
+
+def feature_layers_present(layer_ids, n_blocks=9, n_down=2) -> List[int]:
+    """get_feature_layers silently ignores ids beyond the last numbered activation (generator_resnet_attn.py:204-233)."""
+    return [i for i in range(1 + n_down + n_blocks + n_down) if i in layer_ids]
+
+
+class _InferenceRunner:
+    """Forward-only generator program for ResNetGenerator.forward / get_feature_layers."""
+
+    def __init__(self, module: ResNetGenerator, x: torch.Tensor, dtype: int = F32):
+        assert x.is_cuda, "the MI355X path needs a GPU tensor (there is no CPU fallback)"
+        self.key = (tuple(x.shape), x.device)
+        B, _, H, W = x.shape
+        ops = HipOps(x.device)
+        self.ctx = Ctx(ops, x.device, dtype)
+        sd = {k: v.detach().float().contiguous() for k, v in module.state_dict().items()}
+        self.sd_src = module
+        self.params = {k: v.clone() for k, v in sd.items()}
+        grads = {k: torch.zeros_like(v) for k, v in self.params.items()}
+        self.net = GeneratorNet(self.ctx, self.params, grads, "cut", module.n_blocks, module.ngf, need_input_grad=False)
+        self.gpass = self.net.new_pass(B, H, W)
+        self.xin = torch.zeros(B, 3, H, W, dtype=torch.float32, device=x.device)
+        self.out = torch.zeros(B, 3, H, W, dtype=torch.float32, device=x.device)
+        self.prog = Program("infer")
+        self.prog.add(self.net.repack_program())
+        self.prog.add(self.gpass.fwd_program(self.xin))
+        self.prog.add(ops.view_to_nchw(self.gpass.img, 3, self.out))
+
+    def __call__(self, x, layer_ids):
+        for k, v in self.sd_src.state_dict().items():
+            self.params[k].copy_(v)
+        self.xin.copy_(x)
+        self.prog.run()
+        if layer_ids is None:
+            return self.out.clone()
+        feats = []
+        for i in feature_layers_present(layer_ids, self.net.n_blocks):
+            a = self.gpass.acts[i]
+            t = torch.zeros(a.B, a.C, a.H, a.W, dtype=torch.float32, device=x.device)
+            self.ctx.ops.view_to_nchw(a, a.C, t)()
+            feats.append(t)
+        return feats
+
+
+# ------------------------------------------------------------------------------------------------
+# the trainer
+# ------------------------------------------------------------------------------------------------
+LOSS_SLOTS = {"d_real": 0, "d_fake": 1, "r1": 2, "g_adv": 3, "nce": 4, "identity": 5, "scratch": 6, "idw": 7}
+
+
+class CutTrainer:
+    """Owns parameters, optimiser state, activation buffers and the step programs of one rank.
+
+    train_step(step, photos, monets) reproduces training/train_cutpp.py:206-331 with two legal savings (results
+    unchanged): G(photos) is computed once per step and shared by the D-step, the G-step and the PatchNCE source
+    features (generator weights do not change in between), and the D weight gradients the reference's G-step
+    backward deposits (and its next zero_grad discards) are never computed.
+    """
+
+    def __init__(self, generator: ResNetGenerator, discriminator: MultiscaleDiscriminator, config: dict, batch_size: int, image_size: int,
+                 device="cuda", amp: Optional[bool] = None, ops=None, world_size: int = 1, process_group=None):
+        self.config = config
+        self.B, self.S = batch_size, image_size
+        self.device = torch.device(device)
+        amp = config.get("amp", True) if amp is None else amp
+        self.amp = AMPContext(amp)
+        self.ops = ops if ops is not None else HipOps(self.device)
+        self.ctx = Ctx(self.ops, self.device, self.amp.dtype)
+        self.ctx32 = self.ctx if self.amp.dtype == F32 else Ctx(self.ops, self.device, F32)
+        self.world_size, self.pg = world_size, process_group
+        lw = config["loss_weights"]
+        self.policy = config["diffaugment"].get("policy", ["color", "translation", "cutout"]) if config["diffaugment"].get("enable", False) else None
+        self.aug = DiffAugment(self.policy) if self.policy is not None else None
+        self.generator, self.discriminator = generator, discriminator
+
+        # ---- parameters -> flat fp32 blocks (master weights, grads, Adam moments, EMA shadow)
+        gsd = {k: v.detach().to(self.device, torch.float32) for k, v in generator.state_dict().items()}
+        dsd = {k: v.detach().to(self.device, torch.float32) for k, v in discriminator.state_dict().items()}
+        og, od = get_optimizer_config(config["optim"]["G"]), get_optimizer_config(config["optim"]["D"])
+        self.opt_G = FusedAdam(self.ctx, list(gsd), [v.shape for v in gsd.values()], gsd, og["lr"], og["betas"], 1e-8, og["weight_decay"],
+                               ema_decay=config["ema"]["decay"])
+        self.opt_D = FusedAdam(self.ctx, list(dsd), [v.shape for v in dsd.values()], dsd, od["lr"], od["betas"], 1e-8, od["weight_decay"])
+        for mod, opt in ((generator, self.opt_G), (discriminator, self.opt_D)):   # modules now alias the trained block
+            for k, p in mod.named_parameters():
+                p.data = opt.params[k]
+
+        B, S = self.B, self.S
+        nb, ngf = generator.n_blocks, generator.ngf
+        self.G = GeneratorNet(self.ctx, self.opt_G.params, self.opt_G.grads, "cut", nb, ngf, need_input_grad=True)
+        self.D = DiscriminatorNet(self.ctx, self.opt_D.params, self.opt_D.grads, "cut", ndf=discriminator.ndf, n_layers=discriminator.n_layers)
+        self.D32 = self.D if self.ctx32 is self.ctx else DiscriminatorNet(self.ctx32, self.opt_D.params, self.opt_D.grads, "cut",
+                                                                          ndf=discriminator.ndf, n_layers=discriminator.n_layers)
+        self.nce_layers = feature_layers_present(config["patchnce"]["nce_layers"], nb) if lw["patchnce"] > 0 else []
+        self.P = config["patchnce"]["num_patches"]
+        self.p1 = self.G.new_pass(B, S, S)
+        self.p2 = self.G.new_pass(B, S, S, last_layer=max(self.nce_layers)) if self.nce_layers else None
+        self.p3 = self.G.new_pass(B, S, S)
+        self.d_real, self.d_fake = self.D.new_pass(B, S, S), self.D.new_pass(B, S, S)
+        self.d_r1 = self.D32.new_pass(B, S, S)
+
+        f32 = self.ctx.f32
+        self.photos = torch.zeros(B, 3, S, S, dtype=torch.float32, device=self.device)
+        self.monets = torch.zeros_like(self.photos)
+        self.fake_out = torch.zeros_like(self.photos)
+        self.losses = f32(16)
+        self.prm = {k: f32(B * 12) for k in ("real", "fake_d", "fake_g")}
+        self.nce_hw = [self.p1.acts[i].H * self.p1.acts[i].W for i in self.nce_layers]
+        self.nce_ids = [torch.zeros(min(self.P, hw), dtype=torch.int32, device=self.device) for hw in self.nce_hw]
+        self._build_programs()
+        self.G.repack_program().run()
+        self.D.repack_program().run()
+
+    # ------------------------------------------------------------------ program construction
+    def _slot(self, name) -> torch.Tensor:
+        i = LOSS_SLOTS[name]
+        return self.losses[i:i + 1]
+
+    def _aug_fwd(self, src: View, dst: View, prm) -> list:
+        ops = self.ops
+        if self.aug is None:
+            return [ops.view_copy(src, dst, HALO_ZERO)]
+        return [ops.diffaug_fwd(src, 3, prm, dst, self.ctx.scratch("aug_ws", self.B + 16))]
+
+    def _build_programs(self):
+        cfg, ops, ctx, B, S = self.config, self.ops, self.ctx, self.B, self.S
+        lw = cfg["loss_weights"]
+        gs = 1.0 / self.world_size
+        # ---- shared generator forward
+        self.prog_gfwd = self.p1.fwd_program(self.photos)
+        # photos as a plain C=8 image view (DiffAugment / R1 input)
+        self.photos_v = ctx.view(B, S, S, 8, 0)
+        self.prog_gfwd.add(ops.nchw_to_view(self.photos, 3, self.photos_v, HALO_ZERO))
+
+        # ---- D step (train_cutpp.py:231-254)
+        pd = Program("D-step")
+        pd.add(self._aug_fwd(self.photos_v, self.d_real.x, self.prm["real"]))
+        pd.add(self._aug_fwd(self.p1.img, self.d_fake.x, self.prm["fake_d"]))
+        pd.add(self.d_real.fwd_program())
+        pd.add(self.d_fake.fwd_program())
+        for i, (dp, mode, slot) in enumerate(((self.d_real, 0, "d_real"), (self.d_fake, 1, "d_fake"))):
+            gl = dp.grad_logits_view()
+            pd.add(ops.patch_loss(dp.logits, mode, 0.0, 0.5, self._slot(slot), gl))
+            pd.add(dp.bwd_program(gl, wgrad=True, accumulate=(i == 1)))
+        self.prog_d_compute = pd
+        self.prog_d_update = Program("D-update")
+        self.prog_d_update.add(self.opt_D.step_op(cfg.get("grad_clip_d", 10.0), gs))
+        self.prog_d_update.add(self.D.repack_program())
+
+        # ---- lazy R1 (train_cutpp.py:165-203, 257-263), always fp32 like the reference
+        pr = Program("R1")
+        rp, c32, dnet = self.d_r1, self.ctx32, self.D32
+        if dnet is not self.D:
+            pr.add(dnet.repack_program())
+        pr.add(ops.nchw_to_view(self.photos, 3, rp.x, HALO_ZERO))
+        pr.add(rp.fwd_program())
+        lg = rp.logits
+        ones = dnet.gbuf("r1_ones", B, lg.H, lg.W, lg.C, 2)
+        n_log = B * lg.H * lg.W
+        pr.add(ops.patch_loss(lg, 2, 0.0, -float(n_log), self._slot("scratch"), ones))   # d(sum D)/dlogits = 1
+        deltas: List[View] = []
+        pr.add(rp.bwd_program(ones, wgrad=False, need_input_grad=True, keep=deltas))
+        u = c32.view(B, S, S, 8, 1)
+        scale = cfg["r1"]["gamma"] * cfg["r1"]["every"]
+        pr.add(ops.r1_reduce(rp.g_input, 3, scale, self._slot("r1"), u, c32.scratch("r1_ws", 1024)))
+        # second-order pass: u_{i} = mask_i * (W_i * u_{i-1});  dW_i = wgrad(u_{i-1}, delta_i)
+        for li, conv in enumerate(dnet.convs):
+            delta = deltas[len(deltas) - 1 - li]
+            pr.add(conv.wgrad(u, delta, accumulate=False, bias_too=False))
+            if li == dnet.nconv - 1:
+                break
+            a = rp.acts[li]
+            nxt = c32.view(B, a.H, a.W, a.C, 1)
+            pr.add(conv.fwd(u, nxt, ACT_NONE, mask=a, use_bias=False))
+            u = nxt
+        skip = []
+        for li, conv in enumerate(dnet.convs):   # biases: zero grad except the last one, whose grad is None (skipped)
+            if conv.grad_b is None:
+                continue
+            if li == dnet.nconv - 1:
+                skip.append([k for k, v in self.opt_D.grads.items() if v is conv.grad_b][0])
+            else:
+                pr.add(ops.fill(conv.grad_b, 0.0))
+        self.prog_r1_compute = pr
+        self.prog_r1_update = Program("R1-update")
+        self.prog_r1_update.add(self.opt_D.step_op(cfg.get("grad_clip_d", 10.0), gs, skip=skip))
+        self.prog_r1_update.add(self.D.repack_program())
+
+        # ---- G step (train_cutpp.py:266-308)
+        pg = Program("G-step")
+        dp = self.d_fake
+        pg.add(self._aug_fwd(self.p1.img, dp.x, self.prm["fake_g"]))
+        pg.add(dp.fwd_program())
+        gl = dp.grad_logits_view()
+        pg.add(ops.patch_loss(dp.logits, 2, 0.0, lw["adv"], self._slot("g_adv"), gl))
+        pg.add(dp.bwd_program(gl, wgrad=False, need_input_grad=True))
+        if self.aug is not None:
+            g_adv_img = ctx.view(B, S, S, 8, 0)
+            pg.add(ops.diffaug_bwd(dp.g_input, 3, self.prm["fake_g"], g_adv_img, ctx.scratch("aug_ws", B + 16)))
+        else:
+            g_adv_img = dp.g_input
+        first = True
+        g_img, g_fold, g_img2 = g_adv_img, False, None
+        if self.nce_layers:
+            pg.add(self.p2.fwd_program(self.p1.img))
+            pg.add(ops.fill(self._slot("nce"), 0.0))
+            wl = lw["patchnce"] / len(self.nce_layers)
+            hooks = {}
+            for li, ids in zip(self.nce_layers, self.nce_ids):
+                src, tgt = self.p1.acts[li], self.p2.acts[li]
+                P = ids.numel()
+                ws = ctx.f32(ops.patchnce_ws_floats(B, P, src.C))
+                pg.add(ops.patchnce_fwd(src, tgt, ids, P, src.C, cfg["patchnce"]["temperature"], wl, self._slot("nce"), ws))
+
+                def mk(tgt=tgt, ids=ids, P=P, ws=ws):
+                    def hook(gv: View):
+                        assert (gv.H, gv.W, gv.C) == (tgt.H, tgt.W, tgt.C)
+                        return [ops.patchnce_bwd(tgt, ids, P, tgt.C, cfg["patchnce"]["temperature"], wl, gv, ws)]
+                    return hook
+                hooks[li] = mk()
+            pg.add(self.p2.bwd_program(hooks=hooks, accumulate=False, need_input_grad=True))
+            first = False
+            g_img, g_fold, g_img2 = self.p2.g_input, True, g_adv_img
+        pg.add(self.p1.bwd_program(g_img, g_fold, g_img2, accumulate=not first))
+        self.prog_g_compute = pg
+        # identity (identity_l1.py:6-22): third pass, gradient scaled by the device-resident identity weight
+        pi = Program("G-identity")
+        pi.add(self.p3.fwd_program(self.monets))
+        g_idt = ctx.view(B, S, S, 8, 0)
+        pi.add(ops.l1_loss(self.p3.img, 3, self.monets, 1.0, self._slot("idw"), self._slot("identity"), g_idt, ctx.scratch("l1_ws", 1024)))
+        pi.add(self.p3.bwd_program(g_idt, accumulate=True))
+        self.prog_g_identity = pi
+        self.prog_g_update = Program("G-update")
+        self.prog_g_update.add(self.opt_G.step_op(cfg.get("grad_clip_g", 10.0), gs))
+        self.prog_g_update.add(self.G.repack_program())
+        self.prog_fake_out = Program("fake-out")
+        self.prog_fake_out.add(ops.view_to_nchw(self.p1.img, 3, self.fake_out))
+
+    # ------------------------------------------------------------------ per-step randomness
+    def sample_randomness(self, generator: Optional[torch.Generator] = None) -> dict:
+        """All device-RNG draws of one step, on the CPU generator, in the reference's consumption order."""
+        B, S = self.B, self.S
+        r = {}
+        if self.aug is not None:
+            for k in ("aug_real", "aug_fake_d", "aug_fake_g"):
+                r[k] = self.aug.sample(B, S, S, generator)
+        r["nce_ids"] = [torch.randint(0, hw, (min(self.P, hw),), generator=generator) for hw in self.nce_hw]
+        return r
+
+    def _load_randomness(self, rnd: dict):
+        B, S = self.B, self.S
+        if self.aug is not None:
+            for key, k in (("real", "aug_real"), ("fake_d", "aug_fake_d"), ("fake_g", "aug_fake_g")):
+                self.prm[key].copy_(DiffAugment.to_params(rnd[k], B, S, S).reshape(-1))
+        for dst, ids in zip(self.nce_ids, rnd["nce_ids"]):
+            dst.copy_(ids.to(torch.int32))
+
+    def _allreduce(self, opt: FusedAdam):
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(opt.flat_g, group=self.pg)   # RCCL over xGMI; sum, the optimiser divides by world_size
+
+    # ------------------------------------------------------------------ the step
+    def train_step(self, step: int, photos: torch.Tensor, monets: torch.Tensor, rnd: Optional[dict] = None, sync: bool = True):
+        """One iteration; returns the reference's loss dict (train_cutpp.py:315-323).  sync=False skips the loss read-back
+        (and the NaN check) and returns None."""
+        cfg = self.config
+        lw = cfg["loss_weights"]
+        idw = identity_weight_at(step, cfg)
+        if rnd is None:
+            rnd = self.sample_randomness()
+        self._load_randomness(rnd)
+        self.photos.copy_(photos, non_blocking=True)
+        self.monets.copy_(monets, non_blocking=True)
+        do_r1 = cfg["r1"]["gamma"] > 0 and step % cfg["r1"]["every"] == 0
+        self.losses.zero_()
+        self.losses[LOSS_SLOTS["idw"]] = idw
+        self.prog_gfwd.run()
+        self.prog_d_compute.run()
+        self._allreduce(self.opt_D)
+        self.prog_d_update.run()
+        if do_r1:
+            self.prog_r1_compute.run()
+            self._allreduce(self.opt_D)
+            self.prog_r1_update.run()
+        self.prog_g_compute.run()
+        if idw > 0:
+            self.prog_g_identity.run()
+        self._allreduce(self.opt_G)
+        self.prog_g_update.run()
+        if not sync:
+            return None
+        v = self.losses.tolist()
+        out = {"d_loss": v[0] + v[1], "g_adv": v[3] / lw["adv"] if lw["adv"] != 0 else 0.0, "nce": v[4] / lw["patchnce"] if lw["patchnce"] > 0 else 0.0,
+               "identity": v[5] if idw > 0 else 0.0, "r1": v[2] if do_r1 else 0.0, "identity_weight": idw}
+        out["g_loss"] = lw["adv"] * out["g_adv"] + lw["patchnce"] * out["nce"] + idw * out["identity"]
+        if any(not math.isfinite(x) for k, x in out.items() if k != "identity_weight"):
+            raise ValueError(f"NaN loss detected at step {step}. Training stopped to prevent corruption.")   # train_cutpp.py:326-329
+        return out
+
+    def generated(self) -> torch.Tensor:
+        """G(photos) of the last step as (B,3,H,W) fp32."""
+        self.prog_fake_out.run()
+        return self.fake_out
+
+    def ema_state_dict(self):
+        return {"decay": self.opt_G.ema_decay, "shadow": {k: v.clone() for k, v in self.opt_G.shadow.items()}}
+
+
+def train_step(step, photos, monets, trainer: CutTrainer, rnd=None):
+    """Functional alias with the reference's leading arguments (train_cutpp.py:206-219); the model / optimiser / EMA /
+    AMP / DiffAugment objects the reference passes separately are owned by `trainer`."""
+    return trainer.train_step(step, photos, monets, rnd)

@@ -1,0 +1,333 @@
+"""Device buffers ("halo-NHWC" views), the op layer over the C ABI, and replayable programs.
+
+Every op constructor returns a zero-argument callable with its ctypes arguments prebuilt, so a training step
+is a flat list of kernel launches ("program") replayed on one HIP stream without any Python-side shape logic,
+host synchronisation or allocation -- the same list can be captured into a hipGraph.
+PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, BF16, F32, HALO_NONE, HALO_REFLECT, HALO_ZERO, GanAdamTensor, GanConvDesc, GanView, GanWgradDesc
+
+IN_WS_CHUNKS = 96
+ADAM_CHUNK = 16384
+
+
+def torch_dtype(code: int):
+    return torch.float32 if code == F32 else torch.bfloat16
+
+
+class View:
+    """A [B][H+2h][W+2h][C] activation buffer with a symmetric spatial halo h."""
+
+    def __init__(self, t: torch.Tensor, B: int, H: int, W: int, C_: int, halo: int, dtype: int):
+        self.t, self.B, self.H, self.W, self.C, self.halo, self.dtype = t, B, H, W, C_, halo, dtype
+        self.Hp, self.Wp = H + 2 * halo, W + 2 * halo
+        assert t.numel() == B * self.Hp * self.Wp * C_ and C_ % 8 == 0
+        self._struct = None
+
+    @property
+    def y0(self):
+        return self.halo
+
+    @property
+    def x0(self):
+        return self.halo
+
+    def ptr(self) -> int:
+        return self.t.data_ptr()
+
+    def struct(self) -> GanView:
+        if self._struct is None:
+            self._struct = GanView(self.ptr(), self.B, self.Hp, self.Wp, self.C, self.halo, self.halo, self.H, self.W, self.dtype, 0)
+        return self._struct
+
+    def nhwc(self) -> torch.Tensor:
+        """Logical interior as a (B,H,W,C) tensor view (tests / debugging)."""
+        full = self.t.view(self.B, self.Hp, self.Wp, self.C)
+        return full[:, self.halo:self.halo + self.H, self.halo:self.halo + self.W, :]
+
+    def padded(self) -> torch.Tensor:
+        return self.t.view(self.B, self.Hp, self.Wp, self.C)
+
+
+@dataclass
+class ConvCall:
+    """Python mirror of gan_conv_desc (see include/mi355x_gan.h)."""
+    B: int
+    Ho: int
+    Wo: int
+    Cin: int
+    ntaps: int
+    Nw: int
+    Nst: int
+    x: View
+    in_y0: int
+    in_x0: int
+    in_sy: int
+    in_sx: int
+    tapoff: torch.Tensor
+    w: torch.Tensor
+    bias: Optional[torch.Tensor]
+    out: View
+    out_y0: int
+    out_x0: int
+    out_sy: int
+    out_sx: int
+    act: int = ACT_NONE
+    mask: Optional[View] = None
+    mask_y0: int = 0
+    mask_x0: int = 0
+
+
+@dataclass
+class WgradCall:
+    """Python mirror of gan_wgrad_desc."""
+    B: int
+    Ho: int
+    Wo: int
+    Cx: int
+    ntaps: int
+    N: int
+    nsplit: int
+    x: View
+    x_y0: int
+    x_x0: int
+    x_sy: int
+    x_sx: int
+    tapoff: torch.Tensor
+    g: View
+    g_y0: int
+    g_x0: int
+    g_sy: int
+    g_sx: int
+    part: torch.Tensor
+
+
+Op = Callable[[], None]
+
+
+class Program:
+    """A flat, replayable list of kernel launches."""
+
+    def __init__(self, name: str = ""):
+        self.name, self.ops = name, []  # type: str, List[Op]
+
+    def add(self, op):
+        if op is None:
+            return
+        if isinstance(op, (list, tuple)):
+            for o in op:
+                self.add(o)
+        elif isinstance(op, Program):
+            self.ops.extend(op.ops)
+        else:
+            self.ops.append(op)
+
+    def run(self):
+        for op in self.ops:
+            op()
+
+    def __len__(self):
+        return len(self.ops)
+
+
+class HipOps:
+    """Op constructors bound to libmi355x_gan.so and one HIP stream.  `stream` is a raw hipStream_t handle (int)."""
+
+    is_hip = True
+
+    def __init__(self, device: torch.device, stream: Optional[int] = None):
+        self.lib = _lib.load()
+        self.device = device
+        self.stream = stream  # None: torch's current stream at op-construction time
+        self._keep = []       # ctypes structs referenced by prebuilt calls
+
+    def _s(self):
+        return C.c_void_p(self.stream if self.stream is not None else torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _call(self, name: str, *args) -> Op:
+        fn = getattr(self.lib, name)
+        self._keep.append(args)
+        lib = self.lib
+
+        def op():
+            rc = fn(*args)
+            if rc != 0:
+                raise _lib.GanError(f"{name}: {lib.gan_last_error().decode()}")
+        op.__name__ = name
+        return op
+
+    @staticmethod
+    def _p(t: Optional[torch.Tensor]):
+        return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+    @staticmethod
+    def _v(v: Optional[View]):
+        return C.byref(v.struct()) if v is not None else C.cast(None, _lib.PV)
+
+    # ---- convolution family
+    def conv_igemm(self, c: ConvCall) -> Op:
+        d = GanConvDesc()
+        d.dtype, d.B, d.Ho, d.Wo, d.Cin, d.ntaps, d.Nw, d.Nst = c.x.dtype, c.B, c.Ho, c.Wo, c.Cin, c.ntaps, c.Nw, c.Nst
+        d.in_, d.in_Hp, d.in_Wp, d.in_y0, d.in_x0, d.in_sy, d.in_sx = c.x.ptr(), c.x.Hp, c.x.Wp, c.in_y0, c.in_x0, c.in_sy, c.in_sx
+        d.tapoff, d.w, d.bias = c.tapoff.data_ptr(), c.w.data_ptr(), (c.bias.data_ptr() if c.bias is not None else None)
+        d.out, d.out_Hp, d.out_Wp, d.out_C = c.out.ptr(), c.out.Hp, c.out.Wp, c.out.C
+        d.out_y0, d.out_x0, d.out_sy, d.out_sx, d.act = c.out_y0, c.out_x0, c.out_sy, c.out_sx, c.act
+        if c.mask is not None:
+            assert c.mask.C == c.out.C and c.mask.dtype == c.out.dtype
+            d.mask, d.mask_Hp, d.mask_Wp, d.mask_y0, d.mask_x0 = c.mask.ptr(), c.mask.Hp, c.mask.Wp, c.mask_y0, c.mask_x0
+        d.stats = None
+        assert c.out.dtype == c.x.dtype
+        return self._call("gan_conv_igemm", C.byref(d), self._s())
+
+    def conv_wgrad(self, c: WgradCall) -> Op:
+        d = GanWgradDesc()
+        d.dtype, d.B, d.Ho, d.Wo, d.Cx, d.ntaps, d.N, d.nsplit = c.x.dtype, c.B, c.Ho, c.Wo, c.Cx, c.ntaps, c.N, c.nsplit
+        d.x, d.x_Hp, d.x_Wp, d.x_y0, d.x_x0, d.x_sy, d.x_sx = c.x.ptr(), c.x.Hp, c.x.Wp, c.x_y0, c.x_x0, c.x_sy, c.x_sx
+        d.tapoff, d.g = c.tapoff.data_ptr(), c.g.ptr()
+        d.g_Hp, d.g_Wp, d.g_C, d.g_y0, d.g_x0, d.g_sy, d.g_sx = c.g.Hp, c.g.Wp, c.g.C, c.g_y0, c.g_x0, c.g_sy, c.g_sx
+        d.part = c.part.data_ptr()
+        assert c.g.dtype == c.x.dtype and c.part.numel() >= c.nsplit * c.N * c.ntaps * c.Cx
+        return self._call("gan_conv_wgrad", C.byref(d), self._s())
+
+    def wgrad_reduce(self, part, nsplit, N, ntaps, Cx, N_real, C_real, swap, I2, KK, khw, grad, accumulate) -> Op:
+        return self._call("gan_wgrad_reduce", self._p(part), nsplit, N, ntaps, Cx, N_real, C_real, int(swap), I2, KK, self._p(khw),
+                          self._p(grad), int(accumulate), self._s())
+
+    def pack_weight(self, src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, swap, I2, KK, khw) -> Op:
+        return self._call("gan_pack_weight", self._p(src), self._p(dst), dtype, Nw, ntaps, Cin, N_real, C_real, int(swap), I2, KK,
+                          self._p(khw), self._s())
+
+    def bias_grad(self, g: View, N_real, grad, accumulate, ws) -> Op:
+        return self._call("gan_bias_grad", self._v(g), N_real, self._p(grad), int(accumulate), self._p(ws), self._s())
+
+    # ---- norm / activations / layout
+    def in_stats(self, x: View, eps, stats, ws) -> Op:
+        return self._call("gan_in_stats", self._v(x), C.c_float(eps), self._p(stats), self._p(ws), self._s())
+
+    def in_apply(self, x: View, stats, act, residual: Optional[View], y: View, halo_mode) -> Op:
+        return self._call("gan_in_apply", self._v(x), self._p(stats), act, self._v(residual), self._v(y), halo_mode, self._s())
+
+    def in_bwd(self, x: View, stats, act, gy: View, fold, g2: Optional[View], dx: View, ws) -> Op:
+        return self._call("gan_in_bwd", self._v(x), self._p(stats), act, self._v(gy), int(fold), self._v(g2), self._v(dx), self._p(ws), self._s())
+
+    def fold_add(self, a: Optional[View], b: View, fold, out: View) -> Op:
+        return self._call("gan_fold_add", self._v(a), self._v(b), int(fold), self._v(out), self._s())
+
+    def act_bwd(self, y: View, act, g: View, fold, g2: Optional[View], dx: View) -> Op:
+        return self._call("gan_act_bwd", self._v(y), act, self._v(g), int(fold), self._v(g2), self._v(dx), self._s())
+
+    def nchw_to_view(self, src: torch.Tensor, Cr, dst: View, halo_mode) -> Op:
+        assert src.dtype == torch.float32 and src.is_contiguous()
+        return self._call("gan_nchw_to_view", self._p(src), Cr, self._v(dst), halo_mode, self._s())
+
+    def view_to_nchw(self, src: View, Cr, dst: torch.Tensor) -> Op:
+        assert dst.dtype == torch.float32 and dst.is_contiguous()
+        return self._call("gan_view_to_nchw", self._v(src), Cr, self._p(dst), self._s())
+
+    def view_copy(self, src: View, dst: View, halo_mode) -> Op:
+        return self._call("gan_view_copy", self._v(src), self._v(dst), halo_mode, self._s())
+
+    # ---- augmentation and losses
+    def diffaug_fwd(self, x: View, Cr, prm, y: View, ws) -> Op:
+        return self._call("gan_diffaug_fwd", self._v(x), Cr, self._p(prm), self._v(y), self._p(ws), self._s())
+
+    def diffaug_bwd(self, gy: View, Cr, prm, gx: View, ws) -> Op:
+        return self._call("gan_diffaug_bwd", self._v(gy), Cr, self._p(prm), self._v(gx), self._p(ws), self._s())
+
+    def patch_loss(self, logits: View, mode, target, scale, loss, grad: Optional[View]) -> Op:
+        return self._call("gan_patch_loss", self._v(logits), mode, C.c_float(target), C.c_float(scale), self._p(loss), self._v(grad), self._s())
+
+    def l1_loss(self, x: View, Cr, target_nchw, scale, dev_scale, loss, grad: Optional[View], ws) -> Op:
+        return self._call("gan_l1_loss", self._v(x), Cr, self._p(target_nchw), C.c_float(scale), self._p(dev_scale), self._p(loss),
+                          self._v(grad), self._p(ws), self._s())
+
+    def r1_reduce(self, g: View, Cr, scale, loss, u: Optional[View], ws) -> Op:
+        return self._call("gan_r1_reduce", self._v(g), Cr, C.c_float(scale), self._p(loss), self._v(u), self._p(ws), self._s())
+
+    def patchnce_ws_floats(self, B, P, Cc) -> int:
+        return int(self.lib.gan_patchnce_ws_floats(B, P, Cc))
+
+    def patchnce_fwd(self, src: View, tgt: View, ids, P, Cc, temperature, weight, loss, ws) -> Op:
+        return self._call("gan_patchnce_fwd", self._v(src), self._v(tgt), self._p(ids), P, Cc, C.c_float(temperature), C.c_float(weight),
+                          self._p(loss), self._p(ws), self._s())
+
+    def patchnce_bwd(self, tgt: View, ids, P, Cc, temperature, weight, gtgt: View, ws) -> Op:
+        return self._call("gan_patchnce_bwd", self._v(tgt), self._p(ids), P, Cc, C.c_float(temperature), C.c_float(weight), self._v(gtgt),
+                          self._p(ws), self._s())
+
+    # ---- optimiser
+    def adam_step(self, table, ntensors, chunk_tensor, chunk_off, nchunks, lr, b1, b2, eps, max_norm, grad_scale, ema_decay, norm_out, ws) -> Op:
+        return self._call("gan_adam_step", self._p(table), ntensors, self._p(chunk_tensor), self._p(chunk_off), nchunks, C.c_float(lr),
+                          C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(max_norm), C.c_float(grad_scale), C.c_float(ema_decay),
+                          self._p(norm_out), self._p(ws), self._s())
+
+    def make_adam_table(self, entries: Sequence[dict]) -> torch.Tensor:
+        """entries: dicts with tensors p, g (or None), m, v, ema (or None), step (int32 tensor of 1).  -> device uint8 table."""
+        arr = (GanAdamTensor * len(entries))()
+        for i, e in enumerate(entries):
+            arr[i].p, arr[i].m, arr[i].v = e["p"].data_ptr(), e["m"].data_ptr(), e["v"].data_ptr()
+            arr[i].g = e["g"].data_ptr() if e.get("g") is not None else None
+            arr[i].ema = e["ema"].data_ptr() if e.get("ema") is not None else None
+            arr[i].numel, arr[i].step = e["p"].numel(), e["step"].data_ptr()
+        raw = bytes(arr)
+        return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+
+    def fill(self, t: torch.Tensor, value: float) -> Op:
+        assert t.dtype == torch.float32
+        return self._call("gan_fill_f32", self._p(t), C.c_int64(t.numel()), C.c_float(value), self._s())
+
+    def axpy(self, y: torch.Tensor, x: torch.Tensor, a: float) -> Op:
+        return self._call("gan_axpy_f32", self._p(y), self._p(x), C.c_float(a), C.c_int64(y.numel()), self._s())
+
+    def zero_(self, t: torch.Tensor) -> Op:
+        """Byte-zero of any buffer (hipMemsetAsync through torch, graph-capturable)."""
+        def op():
+            t.zero_()
+        return op
+
+
+class Ctx:
+    """Allocation context: device, operand dtype, op layer and shared scratch workspaces."""
+
+    def __init__(self, ops, device, dtype: int):
+        self.ops, self.device, self.dtype = ops, torch.device(device), dtype
+        self.tdtype = torch_dtype(dtype)
+        self._scratch, self._retired = {}, []
+
+    def view(self, B, H, W, C_, halo=0, dtype: Optional[int] = None) -> View:
+        dt = self.dtype if dtype is None else dtype
+        t = torch.zeros(B * (H + 2 * halo) * (W + 2 * halo) * C_, dtype=torch_dtype(dt), device=self.device)
+        return View(t, B, H, W, C_, halo, dt)
+
+    def f32(self, n, fill=0.0) -> torch.Tensor:
+        return torch.full((int(n),), fill, dtype=torch.float32, device=self.device)
+
+    def i32(self, values) -> torch.Tensor:
+        return torch.tensor(list(values), dtype=torch.int32, device=self.device)
+
+    def scratch(self, name: str, nfloats: int) -> torch.Tensor:
+        """Grow-only shared fp32 workspace (safe to share: all launches are ordered on one stream)."""
+        cur = self._scratch.get(name)
+        if cur is None or cur.numel() < nfloats:
+            if cur is not None:
+                self._retired.append(cur)  # ops built earlier hold its raw pointer
+            cur = torch.zeros(int(nfloats), dtype=torch.float32, device=self.device)
+            self._scratch[name] = cur
+        return cur
+
+
+def cpad(c: int) -> int:
+    """Channel padding rule of halo-NHWC: next power of two >= 8."""
+    p = 8
+    while p < c:
+        p *= 2
+    return p

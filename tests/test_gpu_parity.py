@@ -1,0 +1,215 @@
+"""Parity tests proper (MI355X, through the C ABI): every HIP kernel against its CPU statement / the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from gan_variant_research_amd import BF16, F32
+from gan_variant_research_amd.runtime import Ctx, HipOps, View
+from tests import cases
+from tests.emulator import EmuOps
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def hip_ctx(dtype):
+    return Ctx(HipOps(torch.device(DEV)), DEV, dtype)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("geom", cases.GEOMS)
+def test_conv_geometry_hip(geom, dtype):
+    cases.run_conv_geometry(hip_ctx(dtype), geom, dtype, B=3)
+
+
+# ---------------------------------------------------------------------------------------------- op twins
+class Twin:
+    """The same buffers on CPU (emulator) and GPU (HIP); ops are built on both and every buffer is compared afterwards."""
+
+    def __init__(self, dtype, seed=0):
+        self.dtype = dtype
+        self.c, self.g = Ctx(EmuOps(), "cpu", dtype), hip_ctx(dtype)
+        self.gen = torch.Generator().manual_seed(seed)
+        self.views, self.tensors = [], []
+
+    def view(self, B, H, W, C, halo, rand=True, scale=1.0, zero_halo=False):
+        vc = self.c.view(B, H, W, C, halo)
+        if rand:
+            data = torch.randn(vc.t.shape, generator=self.gen) * scale
+            vc.t.copy_(data.to(vc.t.dtype))
+            if zero_halo and halo:
+                interior = vc.nhwc().clone()
+                vc.t.zero_()
+                vc.nhwc().copy_(interior)
+        vg = self.g.view(B, H, W, C, halo)
+        vg.t.copy_(vc.t)
+        self.views.append((vc, vg))
+        return vc, vg
+
+    def f32(self, data):
+        tc = data.clone().float()
+        tg = tc.to(DEV)
+        self.tensors.append((tc, tg))
+        return tc, tg
+
+    def i32(self, data):
+        tc = torch.as_tensor(data, dtype=torch.int32)
+        return tc, tc.to(DEV)
+
+    def run(self, cpu_ops, gpu_ops):
+        for o in cpu_ops if isinstance(cpu_ops, (list, tuple)) else [cpu_ops]:
+            o()
+        for o in gpu_ops if isinstance(gpu_ops, (list, tuple)) else [gpu_ops]:
+            o()
+        torch.cuda.synchronize()
+
+    def check(self, rtol, atol):
+        for i, (vc, vg) in enumerate(self.views):
+            np.testing.assert_allclose(vg.t.float().cpu().numpy(), vc.t.float().numpy(), rtol=rtol, atol=atol, err_msg=f"view {i}")
+        for i, (tc, tg) in enumerate(self.tensors):
+            np.testing.assert_allclose(tg.cpu().numpy(), tc.numpy(), rtol=rtol, atol=atol, err_msg=f"tensor {i}")
+
+
+TOL = {F32: (2e-5, 2e-5), BF16: (2e-2, 2e-2)}
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 1), (3, 12, 20, 256, 1), (2, 32, 32, 8, 3), (2, 9, 9, 512, 1)])
+def test_instance_norm_twins(shape, dtype):
+    B, H, W, C, halo = shape
+    for act, res, mode in ((1, False, 2), (0, True, 2), (2, False, 1)):
+        tw = Twin(dtype, seed=act)
+        xc, xg = tw.view(B, H, W, C, 0)
+        rc, rg = tw.view(B, H, W, C, halo) if res else (None, None)
+        yc, yg = tw.view(B, H, W, C, halo, rand=False)
+        sc, sg = tw.f32(torch.zeros(B * C * 2))
+        wc, wg = tw.f32(torch.zeros(B * 96 * C * 2 + B * C * 2))
+        tw.run([tw.c.ops.in_stats(xc, 1e-5, sc, wc), tw.c.ops.in_apply(xc, sc, act, rc, yc, mode)],
+               [tw.g.ops.in_stats(xg, 1e-5, sg, wg), tw.g.ops.in_apply(xg, sg, act, rg, yg, mode)])
+        tw.tensors.pop()  # workspace contents are a kernel detail
+        tw.check(*TOL[dtype])
+        # backward: folded padded-domain gradient + second addend
+        gc, gg = tw.view(B, H, W, C, halo, scale=0.5)
+        g2c, g2g = tw.view(B, H, W, C, 0, scale=0.5)
+        dc, dg = tw.view(B, H, W, C, 2, rand=False)
+        fold = halo if H >= 2 * halo + 2 else 0
+        tw.run(tw.c.ops.in_bwd(xc, sc, act, gc, bool(fold), g2c, dc, wc), tw.g.ops.in_bwd(xg, sg, act, gg, bool(fold), g2g, dg, wg))
+        tw.check(TOL[dtype][0] * 5, TOL[dtype][1] * 5)
+        oc, og = tw.view(B, H, W, C, 0, rand=False)
+        tw.run(tw.c.ops.fold_add(g2c, gc, bool(fold), oc), tw.g.ops.fold_add(g2g, gg, bool(fold), og))
+        tw.run(tw.c.ops.act_bwd(yc, 3, gc, bool(fold), g2c, dc), tw.g.ops.act_bwd(yg, 3, gg, bool(fold), g2g, dg))
+        tw.check(TOL[dtype][0] * 5, TOL[dtype][1] * 5)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_layout_and_losses_twins(dtype):
+    B, S = 3, 24
+    tw = Twin(dtype)
+    img_c, img_g = tw.f32(torch.rand(B, 3, S, S, generator=tw.gen) * 2 - 1)
+    for halo, mode in ((3, 2), (1, 1)):
+        vc, vg = tw.view(B, S, S, 8, halo, rand=False)
+        tw.run(tw.c.ops.nchw_to_view(img_c, 3, vc, mode), tw.g.ops.nchw_to_view(img_g, 3, vg, mode))
+        wc, wg = tw.view(B, S, S, 8, halo, rand=False)
+        tw.run(tw.c.ops.view_copy(vc, wc, mode), tw.g.ops.view_copy(vg, wg, mode))
+    oc, og = tw.f32(torch.zeros(B, 3, S, S))
+    tw.run(tw.c.ops.view_to_nchw(vc, 3, oc), tw.g.ops.view_to_nchw(vg, 3, og))
+    # DiffAugment
+    from gan_variant_research_amd.cut import DiffAugment
+    aug = DiffAugment(["color", "translation", "cutout"])
+    prm = DiffAugment.to_params(aug.sample(B, S, S, tw.gen), B, S, S).reshape(-1)
+    pc, pg = tw.f32(prm)
+    xc, xg = tw.view(B, S, S, 8, 0)
+    xc.nhwc()[..., 3:] = 0; xg.t.copy_(xc.t)
+    yc, yg = tw.view(B, S, S, 8, 1, rand=False)
+    wsc, wsg = torch.zeros(64), torch.zeros(64, device=DEV)
+    tw.run(tw.c.ops.diffaug_fwd(xc, 3, pc, yc, wsc), tw.g.ops.diffaug_fwd(xg, 3, pg, yg, wsg))
+    gyc, gyg = tw.view(B, S, S, 8, 0)
+    gxc, gxg = tw.view(B, S, S, 8, 0, rand=False)
+    tw.run(tw.c.ops.diffaug_bwd(gyc, 3, pc, gxc, wsc), tw.g.ops.diffaug_bwd(gyg, 3, pg, gxg, wsg))
+    # patch losses on a logits view, all modes
+    lc, lg = tw.view(B, 6, 6, 8, 0)
+    for mode, tgt in ((0, 0.0), (1, 0.0), (2, 0.0), (3, 1.0), (4, 1.0), (4, 0.0)):
+        sc, sg = tw.f32(torch.zeros(1))
+        gc, gg = tw.view(B, 6, 6, 8, 2, rand=False)
+        tw.run(tw.c.ops.patch_loss(lc, mode, tgt, 0.5, sc, gc), tw.g.ops.patch_loss(lg, mode, tgt, 0.5, sg, gg))
+    # L1 and R1
+    sc, sg = tw.f32(torch.zeros(1)); dsc, dsg = tw.f32(torch.tensor([0.1]))
+    gc, gg = tw.view(B, S, S, 8, 0, rand=False)
+    w1c, w1g = torch.zeros(1024), torch.zeros(1024, device=DEV)
+    tw.run(tw.c.ops.l1_loss(xc, 3, img_c, 1.0, dsc, sc, gc, w1c), tw.g.ops.l1_loss(xg, 3, img_g, 1.0, dsg, sg, gg, w1g))
+    sc, sg = tw.f32(torch.zeros(1))
+    uc, ug = tw.view(B, S, S, 8, 1, rand=False)
+    tw.run(tw.c.ops.r1_reduce(xc, 3, 160.0, sc, uc, w1c), tw.g.ops.r1_reduce(xg, 3, 160.0, sg, ug, w1g))
+    tw.check(*([1e-4, 1e-5] if dtype == F32 else [2e-2, 2e-2]))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 1, 256), (3, 8, 8, 256, 1, 64), (2, 12, 12, 128, 0, 144)])
+def test_patchnce_twins(shape, dtype):
+    B, H, W, C, halo, P = shape
+    tw = Twin(dtype, seed=5)
+    sc, sg = tw.view(B, H, W, C, halo)
+    tc, tg = tw.view(B, H, W, C, halo)
+    tc.t.copy_((sc.t.float() + 0.5 * tc.t.float()).to(tc.t.dtype)); tg.t.copy_(tc.t)
+    ids = torch.randint(0, H * W, (P,), generator=tw.gen)
+    ids[1] = ids[0]; ids[-1] = ids[0]          # duplicates must accumulate
+    ic, ig = tw.i32(ids)
+    lc, lg = tw.f32(torch.zeros(1))
+    gc, gg = tw.view(B, H, W, C, halo, scale=0.01)
+    n = tw.c.ops.patchnce_ws_floats(B, P, C)
+    wc, wg = torch.zeros(n), torch.zeros(n, device=DEV)
+    tw.run([tw.c.ops.patchnce_fwd(sc, tc, ic, P, C, 0.07, 0.25, lc, wc), tw.c.ops.patchnce_bwd(tc, ic, P, C, 0.07, 0.25, gc, wc)],
+           [tw.g.ops.patchnce_fwd(sg, tg, ig, P, C, 0.07, 0.25, lg, wg), tw.g.ops.patchnce_bwd(tg, ig, P, C, 0.07, 0.25, gg, wg)])
+    tw.check(*([2e-4, 2e-6] if dtype == F32 else [2e-2, 2e-3]))
+
+
+def test_adam_twins(golden):
+    """Fused clip+Adam+EMA against the golden vectors of the reference's AMPContext.step_optimizer + EMA.update."""
+    from gan_variant_research_amd.cut import FusedAdam
+    g = golden("cut_optim.npz")
+    ctx = hip_ctx(F32)
+    names = ["a", "b", "z"]
+    init = {k: torch.from_numpy(g[f"p0.{k}"]).to(DEV) for k in names}
+    opt = FusedAdam(ctx, names, [init[k].shape for k in names], init, ema_decay=0.999)
+    step = opt.step_op(10.0)
+    for s in range(3):
+        for k in names:
+            opt.grads[k].copy_(torch.from_numpy(g[f"g{s}.{k}"]))
+        step()
+        torch.cuda.synchronize()
+        for k in names:
+            np.testing.assert_allclose(opt.params[k].cpu().numpy(), g[f"p{s+1}.{k}"], rtol=2e-6, atol=2e-7)
+            np.testing.assert_allclose(opt.shadow[k].cpu().numpy(), g[f"ema{s+1}.{k}"], rtol=2e-6, atol=2e-7)
+    assert opt.steps.tolist() == [3, 3, 3]
+    skip = opt.step_op(10.0, skip=["z"])
+    skip(); torch.cuda.synchronize()
+    assert opt.steps.tolist() == [4, 4, 3]
+
+
+# ---------------------------------------------------------------------------------------------- whole step
+@pytest.mark.parametrize("use_aug", [True, False])
+def test_cut_train_step_fp32_vs_oracle(use_aug):
+    """fp32 (parity) mode: losses within 1e-3 relative of the PyTorch-CPU oracle at steps 0 and 1 (north_star tolerance)."""
+    tr, img, ref_img = cases.run_cut_steps(DEV, HipOps(torch.device(DEV)), use_aug, amp=False, S=64, B=2, tol0=1e-3, tol1=2e-3, atol1=5e-4)
+    np.testing.assert_allclose(img.numpy(), ref_img.numpy(), rtol=1e-3, atol=1e-3)
+
+
+def test_cut_train_step_bf16_vs_oracle():
+    """bf16 throughput mode (fp32 accumulation): same step, tolerance widened to bf16's 8-bit mantissa."""
+    tr, img, ref_img = cases.run_cut_steps(DEV, HipOps(torch.device(DEV)), True, amp=True, S=64, B=2, nsteps=1, tol0=4e-2, ptol=4.5e-4)
+    np.testing.assert_allclose(img.numpy(), ref_img.numpy(), rtol=5e-2, atol=5e-2)
+
+
+def test_generator_module_forward_and_features(golden):
+    """ResNetGenerator.forward / get_feature_layers on HIP vs the golden outputs of the reference modules."""
+    from gan_variant_research_amd import cut as C
+    g = golden("cut_models.npz")
+    C.set_seed(42)
+    gen, disc = C.build_models(cases.small_config(), DEV)
+    x = torch.from_numpy(g["x64"]).to(DEV)
+    np.testing.assert_allclose(gen(x).cpu().numpy(), g["G64"], rtol=1e-3, atol=1e-3)
+    feats = gen.get_feature_layers(x, [0, 4, 8, 12, 16])
+    assert len(feats) == 4
+    for i, f in enumerate(feats):
+        assert list(f.shape) == list(g[f"feat{i}.shape"])
+        np.testing.assert_allclose(f[:, :8, :4, :4].cpu().numpy(), g[f"feat{i}.slice"], rtol=1e-3, atol=1e-3)
