@@ -1,0 +1,179 @@
+"""Benchmark of the hot path: images/sec of the full CUT G+D train step (256x256, batch 16 per GPU) on MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one call of CutTrainer.train_step (GAN_Variant1/training/train_cutpp.py:206-331 of the reference): shared
+G forward, D step (+ lazy R1 every 16th step), G step with PatchNCE and identity loss, fused clip+Adam+EMA updates,
+on synthetic inputs already resident in HBM.  Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     -- the dominant kernel (3x3 256->256 implicit-GEMM conv forward, 77.3 GFLOP per launch at B=16) timed
+                  live with HIP events on the launch stream, against the dense bf16 MFMA peak;
+  cpu_baseline -- the PyTorch-CPU oracle's train step timed on this host's cores on a bounded sample (B=2).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+GFLOP_PER_IMAGE = 935.9     # canonical algorithmic conv FLOPs of one step per image at 256^2 (identity on)
+
+
+def default_config():
+    return {
+        "loss_weights": {"adv": 1.0, "patchnce": 1.0, "identity_warm": 0.1, "identity_final": 0.0},
+        "warmup_steps": 20000, "grad_clip_g": 10.0, "grad_clip_d": 10.0,
+        "patchnce": {"nce_layers": [0, 4, 8, 12, 16], "temperature": 0.07, "num_patches": 256},
+        "r1": {"gamma": 10.0, "every": 16}, "ema": {"decay": 0.999},
+        "diffaugment": {"enable": True, "policy": ["color", "translation", "cutout"]},
+        "model": {"generator": {"ngf": 64, "n_blocks": 9, "n_downsampling": 2, "padding_type": "reflect", "norm": "instance", "activation": "relu"},
+                  "discriminator": {"ndf": 64, "n_layers": 3, "num_scales": 1, "use_spectral_norm": False}},
+        "optim": {"G": {"lr": 2e-4, "betas": [0.5, 0.999], "weight_decay": 0.0}, "D": {"lr": 2e-4, "betas": [0.5, 0.999], "weight_decay": 0.0}},
+    }
+
+
+def dominant_kernel_roofline(trainer, iters=20):
+    """Times the 3x3 256->256 reflect-padded conv forward (conv_igemm_kernel<bf16,2,2,4>) of one residual block with HIP
+    events on the stream it is launched on.  Algorithmic FLOPs per launch = 2*M*N*K, M = B*(S/4)^2, N = 256, K = 2304."""
+    p1, net = trainer.p1, trainer.G
+    conv = net.c_blk[0][0]
+    x, y = p1.acts[2], p1.raw[3][0]
+    ops = conv.fwd(x, y)
+    for _ in range(3):
+        for o in ops:
+            o()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        for o in ops:
+            o()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    m, n, k = x.B * y.H * y.W, conv.cout, conv.cin * 9
+    flops = 2.0 * m * n * k
+    peak = PEAK_BF16_TFLOPS if trainer.amp.enabled else PEAK_F32_TFLOPS
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            "kernel": "conv_igemm_kernel<%s,2,2,4> 3x3 256->256 fwd" % ("bf16" if trainer.amp.enabled else "f32"),
+            "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
+
+
+def cpu_baseline(image_size=256, batch=2, steps=2):
+    """The oracle (oracle/cut_ref.py, checked against the reference) on the host cores: same step, fp32, B=2."""
+    from oracle import cut_ref
+    torch.set_num_threads(os.cpu_count() or 1)
+    cut_ref.set_seed(42)
+    gp, dp = cut_ref.init_generator(), cut_ref.init_discriminator()
+    og, od = cut_ref.AdamState(gp), cut_ref.AdamState(dp)
+    ema = {k: v.detach().clone() for k, v in gp.items()}
+    cfg = cut_ref.default_config()
+    g = torch.Generator().manual_seed(1234)
+    photos = torch.rand(batch, 3, image_size, image_size, generator=g) * 2 - 1
+    monets = torch.rand(batch, 3, image_size, image_size, generator=g) * 2 - 1
+    times = []
+    for step in range(1, steps + 2):   # starts at step 1 (non-R1), first one is warm-up
+        rnd = cut_ref.sample_step_randomness(batch, image_size, image_size, generator=g)
+        t0 = time.time()
+        cut_ref.train_step(step, photos, monets, gp, dp, og, od, ema, cfg, rnd)
+        times.append(time.time() - t0)
+    dt = sum(times[1:]) / len(times[1:])
+    return {"value": round(batch / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} timed steps of the same CUT step at {image_size}x{image_size}, batch {batch}, fp32, after 1 warm-up step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--fp32", action="store_true", help="parity mode (exact fp32 MFMA) instead of bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        pg = dist.group.WORLD
+
+    from gan_variant_research_amd import cut as C
+    cfg = default_config()
+    C.set_seed(42)                                       # identical replicas on every rank
+    gen, disc = C.build_models(cfg, dev)
+    tr = C.CutTrainer(gen, disc, cfg, args.batch, args.size, device=dev, amp=not args.fp32, world_size=world, process_group=pg)
+    g = torch.Generator().manual_seed(1234 + rank)
+    photos = (torch.rand(args.batch, 3, args.size, args.size, generator=g) * 2 - 1).to(dev)
+    monets = (torch.rand(args.batch, 3, args.size, args.size, generator=g) * 2 - 1).to(dev)
+    aug_gen = torch.Generator().manual_seed(99 + rank)   # per-sample DiffAugment draws differ per rank
+    nce_gen = torch.Generator().manual_seed(7)           # PatchNCE ids are shared by the whole (global) batch
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step = 1   # starts at 1: the timed window contains R1 steps at multiples of 16 and the identity warm-up is active
+    last = None
+    for _ in range(args.warmup):
+        last = tr.train_step(step, photos, monets, tr.sample_randomness(aug_gen, nce_gen))
+        step += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = tr.train_step(step, photos, monets, tr.sample_randomness(aug_gen, nce_gen))
+        step += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ips = args.batch * world * args.steps / dt
+        peak = PEAK_F32_TFLOPS if args.fp32 else PEAK_BF16_TFLOPS
+        out = {
+            "metric": "images/sec (G+D train step) 256x256 CUT", "value": round(ips, 3), "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
+            "config": {"workload": f"CUT ResNet-9 G + PatchGAN D + PatchNCE + identity + lazy R1 + DiffAugment, {args.size}x{args.size}, "
+                                   f"batch {args.batch} per GPU (BASELINE.json configs[2])", "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}"},
+            "step_mfma_frac": round(ips / world * GFLOP_PER_IMAGE * (args.size / 256.0) ** 2 / 1e3 / peak, 4),
+            "last_losses": last,
+        }
+        out["roofline"] = dominant_kernel_roofline(tr)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

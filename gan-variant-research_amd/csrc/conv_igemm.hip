@@ -39,9 +39,11 @@ template <> struct Mma<float> {
   static constexpr int EPC = 4;
   static __device__ __forceinline__ void run(const u32x4_t& wa, const u32x4_t& xb, f32x4_t& acc) {
     // lane group g = lane>>4 owns chunk g of this 4-chunk group; step s multiplies element s of every lane's chunk
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wa[s]), __builtin_bit_cast(float, xb[s]), acc, 0, 0, 0);
+    const f32x4_t wv = __builtin_bit_cast(f32x4_t, wa), xv = __builtin_bit_cast(f32x4_t, xb);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, acc, 0, 0, 0);
   }
 };
 

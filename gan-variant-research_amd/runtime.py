@@ -8,6 +8,8 @@ PyTorch is used only for device memory and streams.
 from __future__ import annotations
 
 import ctypes as C
+import os
+import sys
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
 
@@ -157,6 +159,14 @@ class HipOps:
         fn = getattr(self.lib, name)
         self._keep.append(args)
         lib = self.lib
+        if os.environ.get("GAN_DEBUG_SYNC"):   # debugging aid: name every launch and wait for it, so a fault is attributable
+            def dbg():
+                print(f"[gan] {name}", file=sys.stderr, flush=True)
+                rc = fn(*args)
+                if rc != 0:
+                    raise _lib.GanError(f"{name}: {lib.gan_last_error().decode()}")
+                torch.cuda.synchronize()
+            return dbg
 
         def op():
             rc = fn(*args)
@@ -165,16 +175,23 @@ class HipOps:
         op.__name__ = name
         return op
 
-    @staticmethod
-    def _p(t: Optional[torch.Tensor]):
-        return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    # Prebuilt calls hold RAW device pointers: every tensor / view an op captures is pinned here so that it can never be
+    # returned to the caching allocator while a program that uses it is alive.
+    def _p(self, t: Optional[torch.Tensor]):
+        if t is None:
+            return C.c_void_p(0)
+        self._keep.append(t)
+        return C.c_void_p(t.data_ptr())
 
-    @staticmethod
-    def _v(v: Optional[View]):
-        return C.byref(v.struct()) if v is not None else C.cast(None, _lib.PV)
+    def _v(self, v: Optional[View]):
+        if v is None:
+            return C.cast(None, _lib.PV)
+        self._keep.append(v)
+        return C.byref(v.struct())
 
     # ---- convolution family
     def conv_igemm(self, c: ConvCall) -> Op:
+        self._keep.append(c)
         d = GanConvDesc()
         d.dtype, d.B, d.Ho, d.Wo, d.Cin, d.ntaps, d.Nw, d.Nst = c.x.dtype, c.B, c.Ho, c.Wo, c.Cin, c.ntaps, c.Nw, c.Nst
         d.in_, d.in_Hp, d.in_Wp, d.in_y0, d.in_x0, d.in_sy, d.in_sx = c.x.ptr(), c.x.Hp, c.x.Wp, c.in_y0, c.in_x0, c.in_sy, c.in_sx
@@ -189,6 +206,7 @@ class HipOps:
         return self._call("gan_conv_igemm", C.byref(d), self._s())
 
     def conv_wgrad(self, c: WgradCall) -> Op:
+        self._keep.append(c)
         d = GanWgradDesc()
         d.dtype, d.B, d.Ho, d.Wo, d.Cx, d.ntaps, d.N, d.nsplit = c.x.dtype, c.B, c.Ho, c.Wo, c.Cx, c.ntaps, c.N, c.nsplit
         d.x, d.x_Hp, d.x_Wp, d.x_y0, d.x_x0, d.x_sy, d.x_sx = c.x.ptr(), c.x.Hp, c.x.Wp, c.x_y0, c.x_x0, c.x_sy, c.x_sx
@@ -273,6 +291,7 @@ class HipOps:
     def make_adam_table(self, entries: Sequence[dict]) -> torch.Tensor:
         """entries: dicts with tensors p, g (or None), m, v, ema (or None), step (int32 tensor of 1).  -> device uint8 table."""
         arr = (GanAdamTensor * len(entries))()
+        self._keep.append(entries)
         for i, e in enumerate(entries):
             arr[i].p, arr[i].m, arr[i].v = e["p"].data_ptr(), e["m"].data_ptr(), e["v"].data_ptr()
             arr[i].g = e["g"].data_ptr() if e.get("g") is not None else None
@@ -290,6 +309,8 @@ class HipOps:
 
     def zero_(self, t: torch.Tensor) -> Op:
         """Byte-zero of any buffer (hipMemsetAsync through torch, graph-capturable)."""
+        self._keep.append(t)
+
         def op():
             t.zero_()
         return op

@@ -144,22 +144,21 @@ def run_cut_steps(device, ops, use_aug, amp=False, S=32, B=2, nsteps=2, tol0=2e-
         for a, b in zip(rnd["nce_ids"], rnd2["nce_ids"]):
             assert torch.equal(a, b)
         ref = cut_ref.train_step(step, photos, monets, gp, dp, og, od, ema, cfg, rnd)
+        g_before = {k: v.detach().cpu().clone() for k, v in tr.opt_G.params.items()}
         got = tr.train_step(step, photos.to(device), monets.to(device), rnd2)
         for k in ref:
             # step 1: Adam's sign-like first update makes zero-gradient parameters differ by +-lr; g_adv is a
                 # mean of O(1) logits that happens to be ~1e-3, so it gets an absolute tolerance
-                np.testing.assert_allclose(got[k], ref[k], rtol=tol0 if step == 0 else tol1, atol=tol0 * 0.1 if step == 0 else atol1, err_msg=f"step{step} {k}")
+                # g_adv is a mean of O(1) logits that is itself ~1e-2: absolute tolerance on the logit scale.  (At step 0 the last D bias has an
+                # exactly-zero gradient, so Adam's sign-like first update moves it by +-lr on rounding noise alone: SURVEY.md §7.2.)
+                atol = max(tol0 * 0.1 if step == 0 else atol1, 1e-3 if k == "g_adv" else 0.0)
+                np.testing.assert_allclose(got[k], ref[k], rtol=tol0 if step == 0 else tol1, atol=atol, err_msg=f"step{step} {k}")
         if step == 0:
             for k in gp:
                 np.testing.assert_allclose(tr.opt_G.params[k].cpu().numpy(), gp[k].detach().numpy(), rtol=0, atol=ptol, err_msg=k)
             for k in dp:
-                np.testing.assert_allclose(tr.opt_D.params[k].cpu().numpy(), dp[k].detach().numpy(), rtol=0, atol=ptol, err_msg=k)
+                np.testing.assert_allclose(tr.opt_D.params[k].cpu().numpy(), dp[k].detach().numpy(), rtol=0, atol=2 * ptol, err_msg=k)  # two D updates (D-step + R1)
+    # G(photos) of the last step was computed with the weights before that step's update
     img = tr.generated().cpu()
-    ref_img = cut_ref.generator_forward({k: v.detach() for k, v in tr_ref_params(tr).items()}, photos).detach()
+    ref_img = cut_ref.generator_forward(g_before, photos).detach()
     return tr, img, ref_img
-
-
-def tr_ref_params(tr):
-    """the trainer's generator weights BEFORE the last update are gone; compare G(photos) with the oracle on the
-    trainer's own current weights instead (forward-only parity of the whole generator)."""
-    return {k: v.detach().cpu().clone() for k, v in tr.opt_G.params.items()}
