@@ -234,33 +234,49 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict_
   }
 }
 
-// column sums of g over logical pixels: stage 1 -> ws[block][C], stage 2 -> grad
+// column sums of g over logical pixels: stage 1 -> ws[block][C] (16-byte chunk loads, one chunk lane per 4/8 channels),
+// stage 2 -> grad (one block per 32 channels, 8 partial lanes each)
 template <typename T>
-__global__ void bias_grad_stage1(DView g, int npix, float* __restrict__ ws) {
+__global__ __launch_bounds__(256) void bias_grad_stage1(DView g, int npix, int per, float* __restrict__ ws) {
+  constexpr int N = Chunk<T>::N;
+  const int CL = g.C / N, RL = 256 / CL, cl = threadIdx.x % CL, rl = threadIdx.x / CL;
   const T* p = reinterpret_cast<const T*>(g.ptr);
-  const int C = g.C, CB = C < 256 ? C : 256;        // channels handled per block (blockDim = 256)
-  const int rows_per_blk = 256 / CB;
-  const int c = blockIdx.y * CB + threadIdx.x % CB, rl = threadIdx.x / CB;
-  float s = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * rows_per_blk + rl; i < npix; i += (int64_t)gridDim.x * rows_per_blk) {
-    const int b = (int)(i / (g.H * g.W)), r = (int)(i % (g.H * g.W));
-    s += ld1<T>(p + g.pix(b, r / g.W, r % g.W) + c);
+  const int HW = g.H * g.W;
+  const int p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
+  float s[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) s[e] = 0.f;
+  for (int i = p0 + rl; i < p1; i += RL) {
+    const int b = i / HW, r = i - b * HW, y = r / g.W, x = r - y * g.W;
+    float v[N];
+    Chunk<T>::load(p + g.pix(b, y, x) + cl * N, v);
+#pragma unroll
+    for (int e = 0; e < N; ++e) s[e] += v[e];
   }
+  __shared__ float sh[256 * 8];
+#pragma unroll
+  for (int e = 0; e < N; ++e) sh[threadIdx.x * N + e] = s[e];
+  __syncthreads();
+  if (rl == 0) {
+    for (int r = 1; r < RL; ++r)
+#pragma unroll
+      for (int e = 0; e < N; ++e) s[e] += sh[(r * CL + cl) * N + e];
+#pragma unroll
+    for (int e = 0; e < N; ++e) ws[(int64_t)blockIdx.x * g.C + cl * N + e] = s[e];
+  }
+}
+__global__ __launch_bounds__(256) void bias_grad_stage2(const float* __restrict__ ws, int nblk, int C, int N_real, float* __restrict__ grad, int accumulate) {
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), k0 = threadIdx.x >> 5;
+  float s = 0.f;
+  if (c < C)
+    for (int k = k0; k < nblk; k += 8) s += ws[(int64_t)k * C + c];
   __shared__ float sh[256];
   sh[threadIdx.x] = s;
   __syncthreads();
-  if (rl == 0) {
-    float t = 0.f;
-    for (int k = 0; k < rows_per_blk; ++k) t += sh[k * CB + threadIdx.x];
-    ws[(int64_t)blockIdx.x * C + c] = t;
+  if (k0 == 0 && c < N_real) {
+    for (int k = 1; k < 8; ++k) s += sh[k * 32 + (threadIdx.x & 31)];
+    grad[c] = accumulate ? grad[c] + s : s;
   }
-}
-__global__ void bias_grad_stage2(const float* __restrict__ ws, int nblk, int C, int N_real, float* __restrict__ grad, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N_real) return;
-  float s = 0.f;
-  for (int k = 0; k < nblk; ++k) s += ws[(int64_t)k * C + c];
-  grad[c] = accumulate ? grad[c] + s : s;
 }
 
 }  // namespace
@@ -327,12 +343,18 @@ extern "C" int gan_pack_weight(const float* src, void* dst, int dtype, int Nw, i
 
 extern "C" int gan_bias_grad(const gan_view* g, int N_real, float* grad, int accumulate, float* ws, void* stream) {
   GAN_CHECK(gan_check_view(g, "bias_grad.g") == 0, "%s", gan_last_error());
-  GAN_CHECK((g->C <= 256 ? 256 % g->C == 0 : g->C % 256 == 0) && N_real <= g->C && ws && grad, "bias_grad: unsupported C=%d", g->C);
+  const int epc = g->dtype == GAN_F32 ? 4 : 8, cl = g->C / epc;
+  GAN_CHECK(cl <= 256 && (cl & (cl - 1)) == 0 && N_real <= g->C && ws && grad, "bias_grad: unsupported C=%d", g->C);
   const int npix = g->B * g->H * g->W;
-  const int nblk = 256;
+  // ws: fp32 >= 256*max(C,256) floats -> at most min(1024, 65536/C) blocks
+  int nblk = (int)(((int64_t)npix * cl + 2047) / 2048);
+  const int cap = 65536 / g->C < 1024 ? 65536 / g->C : 1024;
+  if (nblk > cap) nblk = cap;
+  if (nblk < 1) nblk = 1;
+  const int per = (npix + nblk - 1) / nblk;
   DView dv = to_dview(g);
-  GAN_DISPATCH_DTYPE(g->dtype, hipLaunchKernelGGL((bias_grad_stage1<T>), dim3(nblk, g->C <= 256 ? 1 : g->C / 256), dim3(256), 0, (hipStream_t)stream, dv, npix, ws);)
-  hipLaunchKernelGGL(bias_grad_stage2, dim3((N_real + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, nblk, g->C, N_real, grad, accumulate);
+  GAN_DISPATCH_DTYPE(g->dtype, hipLaunchKernelGGL((bias_grad_stage1<T>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, dv, npix, per, ws);)
+  hipLaunchKernelGGL(bias_grad_stage2, dim3((g->C + 31) / 32), dim3(256), 0, (hipStream_t)stream, ws, nblk, g->C, N_real, grad, accumulate);
   GAN_LAUNCH_CHECK();
   return 0;
 }

@@ -341,12 +341,21 @@ int check_lanes(const gan_view* v, const char* what) {
   if (v->C % epc != 0 || cl > NTHR || (cl & (cl - 1)) != 0) return gan_set_error(-1, "%s: C=%d unsupported (C/%d must be a power of two <= 256)", what, v->C, epc);
   return 0;
 }
-int nchunks_for(int HW) {
-  int n = HW / 512;
+// row-chunks per image for the statistics passes: ~2048 16-byte loads per block, at most MAXCH (workspace bound)
+int nchunks_for(int HW, int cl) {
+  int64_t n = ((int64_t)HW * cl + 2047) / 2048;
   if (n < 1) n = 1;
   if (n > MAXCH) n = MAXCH;
-  return n;
+  return (int)n;
 }
+// blocks per image for the apply passes (no workspace bound)
+int nblocks_for(int pixels, int cl) {
+  int64_t n = ((int64_t)pixels * cl + 2047) / 2048;
+  if (n < 1) n = 1;
+  if (n > 1024) n = 1024;
+  return (int)n;
+}
+int lanes_of(const gan_view* v) { return v->C / (v->dtype == GAN_F32 ? 4 : 8); }
 int fold_ok(const gan_view* g, int fold) {
   if (!fold) return 0;
   if (g->y0 < 1 || g->x0 < 1 || g->H < 2 * g->y0 + 2 || g->W < 2 * g->x0 + 2 || g->y0 + g->H + g->y0 > g->Hp || g->x0 + g->W + g->x0 > g->Wp)
@@ -364,7 +373,7 @@ extern "C" int gan_in_stats(const gan_view* x, float eps, float* stats, float* w
   VCHK(x, "in_stats.x");
   if (check_lanes(x, "in_stats")) return -1;
   GAN_CHECK(stats && ws, "in_stats: null pointer");
-  const int HW = x->H * x->W, nch = nchunks_for(HW), BC = x->B * x->C;
+  const int HW = x->H * x->W, nch = nchunks_for(HW, lanes_of(x)), BC = x->B * x->C;
   DView dx = to_dview(x);
   hipStream_t s = (hipStream_t)stream;
   GAN_DISPATCH_DTYPE(x->dtype, hipLaunchKernelGGL((in_partial_kernel<T>), dim3(nch, x->B), dim3(NTHR), 0, s, dx, nch, ws);)
@@ -390,8 +399,7 @@ extern "C" int gan_in_apply(const gan_view* x, const float* stats, int act, cons
   if (halo_mode == GAN_HALO_REFLECT)
     GAN_CHECK(y->y0 < y->H && y->x0 < y->W && 2 * y->y0 + y->H <= y->Hp && 2 * y->x0 + y->W <= y->Wp, "in_apply: reflect halo does not fit");
   const int DH = halo_mode == GAN_HALO_REFLECT ? y->H + 2 * y->y0 : y->H, DW = halo_mode == GAN_HALO_REFLECT ? y->W + 2 * y->x0 : y->W;
-  int nblk = (DH * DW + 255) / 256;
-  if (nblk > 128) nblk = 128;
+  const int nblk = nblocks_for(DH * DW, lanes_of(x));
   DView dx = to_dview(x), dy = to_dview(y), dr = residual ? to_dview(residual) : null_dview();
   GAN_DISPATCH_DTYPE(x->dtype, hipLaunchKernelGGL((in_apply_kernel<T>), dim3(nblk, x->B), dim3(NTHR), 0, (hipStream_t)stream, dx, stats, act,
                                                   dr, residual ? 1 : 0, dy, halo_mode, nblk);)
@@ -409,12 +417,11 @@ extern "C" int gan_in_bwd(const gan_view* x, const float* stats, int act, const 
   if (fold_ok(gy, fold)) return -1;
   GAN_CHECK(stats && ws, "in_bwd: null pointer");
   GAN_CHECK(act == GAN_ACT_NONE || act == GAN_ACT_RELU || act == GAN_ACT_LRELU, "in_bwd: unsupported activation %d", act);
-  const int HW = x->H * x->W, nch = nchunks_for(HW), BC = x->B * x->C;
+  const int HW = x->H * x->W, nch = nchunks_for(HW, lanes_of(x)), BC = x->B * x->C;
   float* ws2 = ws + (int64_t)x->B * MAXCH * x->C * 2;
   DView vx = to_dview(x), vg = to_dview(gy), v2 = g2 ? to_dview(g2) : null_dview(), vd = to_dview(dx);
   hipStream_t s = (hipStream_t)stream;
-  int nblk = (HW + 255) / 256;
-  if (nblk > 128) nblk = 128;
+  const int nblk = nblocks_for(HW, lanes_of(x));
   GAN_DISPATCH_DTYPE(x->dtype,
     hipLaunchKernelGGL((in_bwd_partial_kernel<T>), dim3(nch, x->B), dim3(NTHR), 0, s, vx, stats, act, vg, fold, v2, g2 ? 1 : 0, nch, ws);
     hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3((BC + 255) / 256), dim3(256), 0, s, ws, nch, x->C, BC, HW, ws2);
@@ -430,8 +437,7 @@ extern "C" int gan_fold_add(const gan_view* a, const gan_view* b, int fold, cons
   if (a) { VCHK(a, "fold_add.a"); SAME_SHAPE(a, out, "fold_add(a,out)"); }
   if (fold_ok(b, fold)) return -1;
   const int HW = out->H * out->W;
-  int nblk = (HW + 255) / 256;
-  if (nblk > 128) nblk = 128;
+  const int nblk = nblocks_for(HW, lanes_of(out));
   DView va = a ? to_dview(a) : null_dview(), vb = to_dview(b), vo = to_dview(out);
   GAN_DISPATCH_DTYPE(out->dtype, hipLaunchKernelGGL((fold_add_kernel<T>), dim3(nblk, out->B), dim3(NTHR), 0, (hipStream_t)stream, va, a ? 1 : 0,
                                                     vb, fold, null_dview(), GAN_ACT_NONE, vo, nblk);)
@@ -446,8 +452,7 @@ extern "C" int gan_act_bwd(const gan_view* y, int act, const gan_view* g, int fo
   if (g2) { VCHK(g2, "act_bwd.g2"); SAME_SHAPE(y, g2, "act_bwd(y,g2)"); }
   if (fold_ok(g, fold)) return -1;
   const int HW = dx->H * dx->W;
-  int nblk = (HW + 255) / 256;
-  if (nblk > 128) nblk = 128;
+  const int nblk = nblocks_for(HW, lanes_of(dx));
   DView vy = to_dview(y), vg = to_dview(g), v2 = g2 ? to_dview(g2) : null_dview(), vd = to_dview(dx);
   GAN_DISPATCH_DTYPE(dx->dtype, hipLaunchKernelGGL((fold_add_kernel<T>), dim3(nblk, dx->B), dim3(NTHR), 0, (hipStream_t)stream, v2, g2 ? 1 : 0,
                                                    vg, fold, vy, act, vd, nblk);)

@@ -488,14 +488,17 @@ class CutTrainer:
         self.prog_fake_out.add(ops.view_to_nchw(self.p1.img, 3, self.fake_out))
 
     # ------------------------------------------------------------------ per-step randomness
-    def sample_randomness(self, generator: Optional[torch.Generator] = None) -> dict:
-        """All device-RNG draws of one step, on the CPU generator, in the reference's consumption order."""
+    def sample_randomness(self, generator: Optional[torch.Generator] = None, nce_generator: Optional[torch.Generator] = None) -> dict:
+        """All device-RNG draws of one step, on the CPU generator, in the reference's consumption order.
+        Data parallel: DiffAugment draws are per sample (rank-local `generator`), PatchNCE ids are shared by the whole
+        global batch (patchnce_cut.py:63), so every rank passes an identically seeded `nce_generator`."""
         B, S = self.B, self.S
         r = {}
         if self.aug is not None:
             for k in ("aug_real", "aug_fake_d", "aug_fake_g"):
                 r[k] = self.aug.sample(B, S, S, generator)
-        r["nce_ids"] = [torch.randint(0, hw, (min(self.P, hw),), generator=generator) for hw in self.nce_hw]
+        ng = generator if nce_generator is None else nce_generator
+        r["nce_ids"] = [torch.randint(0, hw, (min(self.P, hw),), generator=ng) for hw in self.nce_hw]
         return r
 
     def _load_randomness(self, rnd: dict):
