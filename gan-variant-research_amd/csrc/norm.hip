@@ -83,21 +83,28 @@ __global__ __launch_bounds__(NTHR) void in_partial_kernel(DView x, int nch, floa
     for (int e = 0; e < N; ++e) { o[2 * e] = s[e]; o[2 * e + 1] = q[e]; }
   }
 }
-// stats[(b*C+c)*2] = mean, +1 = rstd
-__global__ void in_finalize_kernel(const float* __restrict__ ws, int nch, int C, int BC, int HW, float eps, float* __restrict__ stats) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= BC) return;
-  const int b = i / C, c = i - b * C;
+// stats[(b*C+c)*2] = mean, +1 = rstd.  One block per 32 (b,c) pairs, 8 partial lanes each.
+__global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ ws, int nch, int C, int BC, int HW, float eps, float* __restrict__ stats) {
+  const int i = blockIdx.x * 32 + (threadIdx.x & 31), k0 = threadIdx.x >> 5;
   double s = 0, q = 0;
-  for (int k = 0; k < nch; ++k) {
-    const float* p = ws + ((int64_t)(b * nch + k) * C + c) * 2;
-    s += p[0]; q += p[1];
+  if (i < BC) {
+    const int b = i / C, c = i - b * C;
+    for (int k = k0; k < nch; k += 8) {
+      const float* p = ws + ((int64_t)(b * nch + k) * C + c) * 2;
+      s += p[0]; q += p[1];
+    }
   }
-  const double mean = s / HW;
-  double var = q / HW - mean * mean;
-  if (var < 0) var = 0;
-  stats[2 * i] = (float)mean;
-  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  __shared__ double sh[512];
+  sh[threadIdx.x * 2] = s; sh[threadIdx.x * 2 + 1] = q;
+  __syncthreads();
+  if (k0 == 0 && i < BC) {
+    for (int k = 1; k < 8; ++k) { s += sh[(k * 32 + threadIdx.x) * 2]; q += sh[(k * 32 + threadIdx.x) * 2 + 1]; }
+    const double mean = s / HW;
+    double var = q / HW - mean * mean;
+    if (var < 0) var = 0;
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 __global__ void in_finalize_inplace_kernel(float* __restrict__ stats, int BC, int HW, float eps) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,17 +214,24 @@ __global__ __launch_bounds__(NTHR) void in_bwd_partial_kernel(DView x, const flo
   }
 }
 // ws2[(b*C+c)*2] = mean(g), +1 = mean(g*xhat)
-__global__ void in_bwd_finalize_kernel(const float* __restrict__ ws, int nch, int C, int BC, int HW, float* __restrict__ ws2) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= BC) return;
-  const int b = i / C, c = i - b * C;
+__global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const float* __restrict__ ws, int nch, int C, int BC, int HW, float* __restrict__ ws2) {
+  const int i = blockIdx.x * 32 + (threadIdx.x & 31), k0 = threadIdx.x >> 5;
   double s = 0, q = 0;
-  for (int k = 0; k < nch; ++k) {
-    const float* p = ws + ((int64_t)(b * nch + k) * C + c) * 2;
-    s += p[0]; q += p[1];
+  if (i < BC) {
+    const int b = i / C, c = i - b * C;
+    for (int k = k0; k < nch; k += 8) {
+      const float* p = ws + ((int64_t)(b * nch + k) * C + c) * 2;
+      s += p[0]; q += p[1];
+    }
   }
-  ws2[2 * i] = (float)(s / HW);
-  ws2[2 * i + 1] = (float)(q / HW);
+  __shared__ double sh[512];
+  sh[threadIdx.x * 2] = s; sh[threadIdx.x * 2 + 1] = q;
+  __syncthreads();
+  if (k0 == 0 && i < BC) {
+    for (int k = 1; k < 8; ++k) { s += sh[(k * 32 + threadIdx.x) * 2]; q += sh[(k * 32 + threadIdx.x) * 2 + 1]; }
+    ws2[2 * i] = (float)(s / HW);
+    ws2[2 * i + 1] = (float)(q / HW);
+  }
 }
 template <typename T>
 __global__ __launch_bounds__(NTHR) void in_bwd_apply_kernel(DView x, const float* __restrict__ stats, int act, DView gy, int fold, DView g2,
@@ -377,7 +391,7 @@ extern "C" int gan_in_stats(const gan_view* x, float eps, float* stats, float* w
   DView dx = to_dview(x);
   hipStream_t s = (hipStream_t)stream;
   GAN_DISPATCH_DTYPE(x->dtype, hipLaunchKernelGGL((in_partial_kernel<T>), dim3(nch, x->B), dim3(NTHR), 0, s, dx, nch, ws);)
-  hipLaunchKernelGGL(in_finalize_kernel, dim3((BC + 255) / 256), dim3(256), 0, s, ws, nch, x->C, BC, HW, eps, stats);
+  hipLaunchKernelGGL(in_finalize_kernel, dim3((BC + 31) / 32), dim3(256), 0, s, ws, nch, x->C, BC, HW, eps, stats);
   GAN_LAUNCH_CHECK();
   return 0;
 }
@@ -424,7 +438,7 @@ extern "C" int gan_in_bwd(const gan_view* x, const float* stats, int act, const 
   const int nblk = nblocks_for(HW, lanes_of(x));
   GAN_DISPATCH_DTYPE(x->dtype,
     hipLaunchKernelGGL((in_bwd_partial_kernel<T>), dim3(nch, x->B), dim3(NTHR), 0, s, vx, stats, act, vg, fold, v2, g2 ? 1 : 0, nch, ws);
-    hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3((BC + 255) / 256), dim3(256), 0, s, ws, nch, x->C, BC, HW, ws2);
+    hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3((BC + 31) / 32), dim3(256), 0, s, ws, nch, x->C, BC, HW, ws2);
     hipLaunchKernelGGL((in_bwd_apply_kernel<T>), dim3(nblk, x->B), dim3(NTHR), 0, s, vx, stats, act, vg, fold, v2, g2 ? 1 : 0, ws2, vd, nblk);)
   GAN_LAUNCH_CHECK();
   return 0;
