@@ -72,7 +72,9 @@ def dominant_kernel_roofline(trainer, iters=20):
 def cpu_baseline(image_size=256, batch=2, steps=2):
     """The oracle (oracle/cut_ref.py, checked against the reference) on the host cores: same step, fp32, B=2."""
     from oracle import cut_ref
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives one job a share of the host (16 cores per GPU): never oversubscribe it
+    ncores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    torch.set_num_threads(ncores)
     cut_ref.set_seed(42)
     gp, dp = cut_ref.init_generator(), cut_ref.init_discriminator()
     og, od = cut_ref.AdamState(gp), cut_ref.AdamState(dp)
@@ -87,6 +89,7 @@ def cpu_baseline(image_size=256, batch=2, steps=2):
         t0 = time.time()
         cut_ref.train_step(step, photos, monets, gp, dp, og, od, ema, cfg, rnd)
         times.append(time.time() - t0)
+        print(f"[bench] cpu_baseline step {step}: {times[-1]:.2f} s on {ncores} threads", file=sys.stderr, flush=True)
     dt = sum(times[1:]) / len(times[1:])
     return {"value": round(batch / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{steps} timed steps of the same CUT step at {image_size}x{image_size}, batch {batch}, fp32, after 1 warm-up step"}
@@ -166,6 +169,7 @@ def main():
             "last_losses": last,
         }
         out["roofline"] = dominant_kernel_roofline(tr)
+        print(f"[bench] gpu: {ips:.1f} images/s, {dt / args.steps * 1e3:.2f} ms/step; roofline {out['roofline']['achieved']} TFLOP/s", file=sys.stderr, flush=True)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(out), flush=True)
