@@ -28,7 +28,7 @@ class GanConvDesc(C.Structure):
                 ("in_", vp), ("in_Hp", i32), ("in_Wp", i32), ("in_y0", i32), ("in_x0", i32), ("in_sy", i32), ("in_sx", i32),
                 ("tapoff", vp), ("w", vp), ("bias", vp), ("out", vp),
                 ("out_Hp", i32), ("out_Wp", i32), ("out_C", i32), ("out_y0", i32), ("out_x0", i32), ("out_sy", i32), ("out_sx", i32),
-                ("act", i32), ("mask", vp), ("mask_Hp", i32), ("mask_Wp", i32), ("mask_y0", i32), ("mask_x0", i32), ("stats", vp)]
+                ("act", i32), ("mask", vp), ("mask_Hp", i32), ("mask_Wp", i32), ("mask_y0", i32), ("mask_x0", i32), ("stats", vp), ("max_tapoff", i32), ("w_layout", i32)]
 
 
 class GanWgradDesc(C.Structure):
@@ -52,7 +52,8 @@ PROTOTYPES = {
     "gan_conv_igemm": (C.c_int, [PC, vp]),
     "gan_conv_wgrad": (C.c_int, [PW, vp]),
     "gan_wgrad_reduce": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
-    "gan_pack_weight": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "gan_conv_patch_ok": (C.c_int, [PC]),
+    "gan_pack_weight": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "gan_bias_grad": (C.c_int, [PV, C.c_int, vp, C.c_int, vp, vp]),
     "gan_in_stats": (C.c_int, [PV, f32, vp, vp, vp]),
     "gan_in_finalize": (C.c_int, [vp, C.c_int, C.c_int, f32, vp]),

@@ -37,12 +37,39 @@ class _Pack:
         self.ntaps = nt
         self.nw = _nw(n_real)
         self.khw = ctx.i32([t[2] for t in taps] + [-1] * (nt - len(taps)))
-        self.w = torch.zeros(self.nw * nt * self.cred, dtype=ctx.tdtype, device=ctx.device)
+        self._w = None     # row-major copy (generic kernel), allocated on first use
+        self._wf = None    # fragment-major copy (range-patch kernel), allocated on first use
         self._tapoff = {}
 
-    def pack_op(self, master: torch.Tensor):
-        return self.ctx.ops.pack_weight(master, self.w, self.ctx.dtype, self.nw, self.ntaps, self.cred, self.n_real, self.c_real, self.swap,
-                                        self.i2, self.kk, self.khw)
+    @property
+    def w(self) -> torch.Tensor:
+        if self._w is None:
+            self._w = torch.zeros(self.nw * self.ntaps * self.cred, dtype=self.ctx.tdtype, device=self.ctx.device)
+        return self._w
+
+    @property
+    def wf(self) -> torch.Tensor:
+        if self._wf is None:
+            self._wf = torch.zeros(self.nw * self.ntaps * self.cred, dtype=self.ctx.tdtype, device=self.ctx.device)
+        return self._wf
+
+    def pack_ops(self, master: torch.Tensor):
+        """Refreshes every operand copy that some planned call uses (plan all calls BEFORE building the repack program)."""
+        out = []
+        for buf, layout in ((self._w, 0), (self._wf, 1)):
+            if buf is not None:
+                out.append(self.ctx.ops.pack_weight(master, buf, self.ctx.dtype, self.nw, self.ntaps, self.cred, self.n_real, self.c_real,
+                                                    self.swap, self.i2, self.kk, self.khw, layout))
+        return out
+
+    def finalize(self, c: ConvCall) -> ConvCall:
+        """Picks the kernel for a planned call: range-patch (fragment-major weight copy) if it qualifies, else generic."""
+        c.w = None
+        if self.ctx.ops.conv_patch_ok(c):
+            c.w, c.w_frag = self.wf, True
+        else:
+            c.w, c.w_frag = self.w, False
+        return c
 
     def tapoff(self, wp: int) -> torch.Tensor:
         t = self._tapoff.get(wp)
@@ -50,6 +77,9 @@ class _Pack:
             t = self.ctx.i32([(dy * wp + dx) * self.cred for dy, dx, _ in self.taps] + [0] * (self.ntaps - len(self.taps)))
             self._tapoff[wp] = t
         return t
+
+    def max_tapoff(self, wp: int) -> int:
+        return max((dy * wp + dx) * self.cred for dy, dx, _ in self.taps)
 
 
 def _phase_taps(k: int, p: int, r: int):
@@ -116,7 +146,7 @@ class ConvLayer:
 
     # ------------------------------------------------------------------ weights
     def repack_ops(self):
-        out = [pk.pack_op(self.weight) for pk in self.packs]
+        out = [op for pk in self.packs for op in pk.pack_ops(self.weight)]
         if self.bias_k is not self.bias:
             out.append(self.ctx.ops.pack_weight(self.bias, self.bias_k, F32, self.bias_k.numel(), 1, 1, self.cout, 1, False, 1, 1, self._one))
         return out
@@ -130,9 +160,9 @@ class ConvLayer:
             ho, wo = (x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1
             assert (ho, wo) == (y.H, y.W) and x.halo >= p, (ho, wo, y.H, y.W, x.halo, p)
             pk = self.fwd_pack
-            return [ops.conv_igemm(ConvCall(x.B, ho, wo, pk.cred, pk.ntaps, pk.nw, min(pk.nw, y.C), x, x.halo - p, x.halo - p, s, s,
-                                            pk.tapoff(x.Wp), pk.w, self.bias_k if use_bias else None, y, y.halo, y.halo, 1, 1, act, mask,
-                                            mask.halo if mask else 0, mask.halo if mask else 0))]
+            return [ops.conv_igemm(pk.finalize(ConvCall(x.B, ho, wo, pk.cred, pk.ntaps, pk.nw, min(pk.nw, y.C), x, x.halo - p, x.halo - p, s, s,
+                                            pk.tapoff(x.Wp), None, self.bias_k if use_bias else None, y, y.halo, y.halo, 1, 1, act, mask,
+                                            mask.halo if mask else 0, mask.halo if mask else 0, pk.max_tapoff(x.Wp))))]
         assert (y.H, y.W) == (2 * x.H, 2 * x.W)
         return self._phased(self.fwd_packs, x, y, act, self.bias_k if use_bias else None, mask)
 
@@ -144,9 +174,9 @@ class ConvLayer:
             (ry, rx), (dmy, dmx), (dxy, dxx) = pk.phase, pk.dmin, pk.dmax
             assert src.halo + dmy >= 0 and src.halo + dmx >= 0, "source halo too small (top/left)"
             assert gh - 1 + dxy <= src.H - 1 + src.halo and gw - 1 + dxx <= src.W - 1 + src.halo, "source halo too small (bottom/right)"
-            out.append(ops.conv_igemm(ConvCall(src.B, gh, gw, pk.cred, pk.ntaps, pk.nw, min(pk.nw, dst.C), src, src.halo + dmy, src.halo + dmx,
-                                               1, 1, pk.tapoff(src.Wp), pk.w, bias, dst, dst.halo + ry, dst.halo + rx, 2, 2, act, mask,
-                                               (mask.halo + ry) if mask else 0, (mask.halo + rx) if mask else 0)))
+            out.append(ops.conv_igemm(pk.finalize(ConvCall(src.B, gh, gw, pk.cred, pk.ntaps, pk.nw, min(pk.nw, dst.C), src, src.halo + dmy, src.halo + dmx,
+                                               1, 1, pk.tapoff(src.Wp), None, bias, dst, dst.halo + ry, dst.halo + rx, 2, 2, act, mask,
+                                               (mask.halo + ry) if mask else 0, (mask.halo + rx) if mask else 0, pk.max_tapoff(src.Wp)))))
         return out
 
     # ------------------------------------------------------------------ input gradient
@@ -157,9 +187,9 @@ class ConvLayer:
         if self.transposed:  # regular strided conv over dy
             pk = self.dgrad_pack
             assert dy.halo >= p and (dy.H, dy.W) == (2 * dx.H, 2 * dx.W) and not padded_domain
-            return [ops.conv_igemm(ConvCall(dy.B, dx.H, dx.W, pk.cred, pk.ntaps, pk.nw, min(pk.nw, dx.C), dy, dy.halo - p, dy.halo - p, 2, 2,
-                                            pk.tapoff(dy.Wp), pk.w, None, dx, dx.halo, dx.halo, 1, 1, ACT_NONE, mask,
-                                            mask.halo if mask else 0, mask.halo if mask else 0))]
+            return [ops.conv_igemm(pk.finalize(ConvCall(dy.B, dx.H, dx.W, pk.cred, pk.ntaps, pk.nw, min(pk.nw, dx.C), dy, dy.halo - p, dy.halo - p, 2, 2,
+                                            pk.tapoff(dy.Wp), None, None, dx, dx.halo, dx.halo, 1, 1, ACT_NONE, mask,
+                                            mask.halo if mask else 0, mask.halo if mask else 0, pk.max_tapoff(dy.Wp))))]
         if self.s == 1:
             pk = self.dgrad_packs[0]
             if padded_domain:
@@ -169,8 +199,8 @@ class ConvLayer:
                 assert dy.halo >= k - 1 - p
                 gh, gw, oy, iy = dx.H, dx.W, dx.halo, dy.halo - (k - 1) + p
             assert gh == dy.H + k - 1 - (0 if padded_domain else 2 * p), (gh, dy.H, k, p)
-            return [ops.conv_igemm(ConvCall(dy.B, gh, gw, pk.cred, pk.ntaps, pk.nw, min(pk.nw, dx.C), dy, iy, iy, 1, 1, pk.tapoff(dy.Wp), pk.w,
-                                            None, dx, oy, oy, 1, 1, ACT_NONE, mask, mask.halo if mask else 0, mask.halo if mask else 0))]
+            return [ops.conv_igemm(pk.finalize(ConvCall(dy.B, gh, gw, pk.cred, pk.ntaps, pk.nw, min(pk.nw, dx.C), dy, iy, iy, 1, 1, pk.tapoff(dy.Wp), None,
+                                            None, dx, oy, oy, 1, 1, ACT_NONE, mask, mask.halo if mask else 0, mask.halo if mask else 0, pk.max_tapoff(dy.Wp))))]
         assert not padded_domain and (dx.H, dx.W) == (2 * dy.H, 2 * dy.W)
         return self._phased(self.dgrad_packs, dy, dx, ACT_NONE, None, mask)
 

@@ -14,6 +14,7 @@
 //    output channels of one pixel -> one 8/16-byte store per 16x16 tile, bias/activation fused;
 //  * bf16 path: v_mfma_f32_16x16x32_bf16; fp32 (parity) path: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain);
 //  * block id -> tile mapping keeps all N-tiles of one M-tile on one XCD (shared A tile served from that L2).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -26,6 +27,7 @@ struct ConvArgs {
   int out_Hp, out_Wp, out_C, out_y0, out_x0, out_sy, out_sx;
   int Nst, act, MT, NTILES;
   int mask_Hp, mask_Wp, mask_y0, mask_x0;
+  int dbg;  // timing-only ablations (GAN_CONV_DEBUG): 1 skip A staging after step 0, 2 skip B staging, 4 skip MFMA
 };
 
 template <typename T> struct Mma;
@@ -93,12 +95,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
     char* sb = sa + BM * 128;
     const int kk = ks * BKE + cc * EPC;
     const uint32_t koff = (uint32_t)(taptab[kk >> a.lgCin] + (kk & (a.Cin - 1))) * (uint32_t)sizeof(T);
+    if (!((a.dbg & 1) && ks > 0)) {
 #pragma unroll
-    for (int i = 0; i < AI; ++i) glds16(a.in, a_row[i] + koff, sa + lds_thr + i * (RSTEP * 128));
+      for (int i = 0; i < AI; ++i) glds16(a.in, a_row[i] + koff, sa + lds_thr + i * (RSTEP * 128));
+    }
     const uint32_t kb = (uint32_t)(ks * BKE) * (uint32_t)sizeof(T);
+    if (!((a.dbg & 2) && ks > 0)) {
 #pragma unroll
-    for (int i = 0; i < BI; ++i)
-      if (BN >= RSTEP * (i + 1) || rr + RSTEP * i < BN) glds16(a.w, b_row[i] + kb, sb + lds_thr + i * (RSTEP * 128));
+      for (int i = 0; i < BI; ++i)
+        if (BN >= RSTEP * (i + 1) || rr + RSTEP * i < BN) glds16(a.w, b_row[i] + kb, sb + lds_thr + i * (RSTEP * 128));
+    }
   };
 
   const int wm = wave / WN, wn = wave % WN;
@@ -117,10 +123,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
   for (int j = 0; j < NT; ++j) wb[j] = (uint32_t)(BM * 128 + (wn * NT * 16 + j * 16 + fr) * 128);
 
+  const int nk = (a.dbg & 8) ? 1 : a.nk;  // dbg 8: prologue + one K-step + epilogue only
   stage(0, 0);
-  for (int ks = 0; ks < a.nk; ++ks) {
+  for (int ks = 0; ks < nk; ++ks) {
     __syncthreads();  // stage ks landed (vmcnt(0) + barrier); everyone is done reading the other buffer
-    if (ks + 1 < a.nk) stage(ks + 1, (ks + 1) & 1);
+    if (ks + 1 < nk) stage(ks + 1, (ks + 1) & 1);
     const char* sbuf = lds + (ks & 1) * STAGE;
 #pragma unroll
     for (int kq = 0; kq < 2; ++kq) {
@@ -130,6 +137,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
       for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const u32x4_t*>(sbuf + xa[i] + co);
 #pragma unroll
       for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const u32x4_t*>(sbuf + wb[j] + co);
+      if (a.dbg & 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(xf[i]));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(wf[j]));
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -162,6 +176,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= (ld1<T>(mask + mb + n + e) > 0.f ? 1.f : 0.2f);
       }
+      if (a.dbg & 16) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
       if constexpr (sizeof(T) == 4) {
         *reinterpret_cast<f32x4_t*>(out + ob + n) = f32x4_t{v[0], v[1], v[2], v[3]};
       } else {
@@ -188,6 +203,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
+int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s);
+
 extern "C" int gan_conv_igemm(const gan_conv_desc* d, void* stream) {
   GAN_CHECK(d, "conv: null descriptor");
   GAN_CHECK(d->dtype == GAN_F32 || d->dtype == GAN_BF16, "conv: bad dtype %d", d->dtype);
@@ -210,6 +227,8 @@ extern "C" int gan_conv_igemm(const gan_conv_desc* d, void* stream) {
             "conv: input window outside the allocation");
   GAN_CHECK(d->out_y0 >= 0 && d->out_x0 >= 0 && (d->Ho - 1) * d->out_sy + d->out_y0 < d->out_Hp && (d->Wo - 1) * d->out_sx + d->out_x0 < d->out_Wp,
             "conv: output window outside the allocation");
+  if (d->w_layout == 1) return gan_conv_patch_launch(d, (hipStream_t)stream);
+  GAN_CHECK(d->w_layout == 0, "conv: bad w_layout %d", d->w_layout);
   ConvArgs a;
   a.in = (const char*)d->in; a.w = (const char*)d->w; a.bias = d->bias; a.out = (char*)d->out; a.mask = (const char*)d->mask;
   a.tapoff = d->tapoff; a.stats = d->stats;
@@ -219,6 +238,7 @@ extern "C" int gan_conv_igemm(const gan_conv_desc* d, void* stream) {
   a.out_Hp = d->out_Hp; a.out_Wp = d->out_Wp; a.out_C = d->out_C; a.out_y0 = d->out_y0; a.out_x0 = d->out_x0;
   a.out_sy = d->out_sy; a.out_sx = d->out_sx;
   a.Nst = d->Nst; a.act = d->act; a.MT = 0; a.NTILES = 0;
+  { const char* e = getenv("GAN_CONV_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   a.mask_Hp = d->mask_Hp; a.mask_Wp = d->mask_Wp; a.mask_y0 = d->mask_y0; a.mask_x0 = d->mask_x0;
   hipStream_t s = (hipStream_t)stream;
   // tile choice by the packed weight height (the packer pads Nw to the tile the launcher will use)

@@ -1,0 +1,311 @@
+// "Range-patch" implicit-GEMM convolution: the fast path of gan_conv_igemm for windows on narrow maps with >= 64 input
+// channels (the 18 residual 3x3 256->256 convolutions and their input gradients -- 40 % of the CUT step -- the
+// transposed-conv phases and the last discriminator layers).
+//
+// Measurements on gfx950 (profiles/) showed the generic kernel (conv_igemm.hip) is neither bandwidth- nor
+// bank-conflict-bound: its K-loop is LATENCY-bound by one block-wide barrier per 128-byte K-step around small dependent
+// LDS read batches, and a third of its time is per-tile prologue/epilogue.  This kernel is built around removing
+// synchronisation instead:
+//  * A operand: the pixels a 256-row tile needs for ALL taps form one contiguous range of the halo-NHWC image (GEMM rows
+//    are consecutive pixels, taps are constant pixel offsets).  One 64-channel slab of that range (<= 448 pixels x 128 B)
+//    is staged into LDS once and every tap reads its fragments from it at a shifted row -> ONE barrier per slab (288 MFMA
+//    per wave) instead of one per tap-step, and ~6x less global->LDS traffic for 3x3 windows;
+//  * W operand: never touches LDS.  The weights are packed "fragment-major" ([n/16][k/32][lane][8 bf16], see
+//    gan_pack_weight layout 1), so a wave fetches each MFMA A-fragment with one fully coalesced 1 KB global_load_dwordx4
+//    straight from L2/L1 into operand registers, prefetched one whole tap (two MFMA k-steps) ahead in a second register set;
+//  * one persistent 512-thread block per CU (8 waves = 4(M) x 2(N), each 64x64 of v_mfma_f32_16x16x32_bf16) walks its
+//    256x128 tiles as one software pipeline: the next slab (or the next tile's first slab) is fetched to registers and
+//    written to the other LDS buffer while the current one computes, so tile boundaries cost no load latency;
+//  * all global loads are plain VGPR loads (no LDS-DMA), so hipcc's counted s_waitcnt vmcnt(N) keeps the prefetch in flight;
+//  * the epilogue pairs lanes 16 apart (same pixel, adjacent channel quads) and writes 16-byte stores.
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+struct PatchArgs {
+  const char* in; const char* w; const float* bias; char* out; const char* mask; const int32_t* tapoff;
+  int B, M_img, Wo, MT_img, NTILES, tiles;
+  int Cin, nchunk, ntaps, KB;                             // KB = Ktot/32 fragment blocks per 16-row weight tile
+  int in_Hp, in_Wp, in_y0, in_x0, in_sy, in_sx, in_pix;   // in_pix: pixels in the whole input tensor
+  int out_Hp, out_Wp, out_C, out_y0, out_x0, out_sy, out_sx;
+  int Nst, act;
+  int mask_Hp, mask_Wp, mask_y0, mask_x0;
+  int w_bytes;
+  unsigned long long* stamps;   // diagnostic build only (GAN_PATCH_STAMPS): [block][32] s_memtime stamps of wave 0
+};
+
+constexpr int BM = 256, BN = 128, NTHR = 512;
+constexpr int RMAX = 448;                    // pixels per patch buffer (7 slices of 64)
+constexpr int NSLICE = RMAX / 64;
+constexpr int PATCHB = RMAX * 128;
+constexpr int LDS_BYTES = 2 * PATCHB + 512;
+
+struct TileGeo { int b, m0, n0, P0; };
+
+__device__ __forceinline__ int pixbase(const PatchArgs& a, int b, int m) {
+  const int ho = m / a.Wo, wo = m - ho * a.Wo;
+  return (b * a.in_Hp + ho * a.in_sy + a.in_y0) * a.in_Wp + wo * a.in_sx + a.in_x0;
+}
+__device__ __forceinline__ TileGeo tile_geo(const PatchArgs& a, int tau) {
+  TileGeo g;
+  const int mt = tau / a.NTILES;
+  g.n0 = (tau - mt * a.NTILES) * BN;
+  g.b = mt / a.MT_img;
+  g.m0 = (mt - g.b * a.MT_img) * BM;
+  g.P0 = pixbase(a, g.b, g.m0);
+  return g;
+}
+
+__global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  char* pbuf = lds;                       // [2][PATCHB]
+  int32_t* taptab = reinterpret_cast<int32_t*>(lds + 2 * PATCHB);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < a.ntaps; i += NTHR) taptab[i] = a.tapoff[i] / a.Cin;   // pixel offsets
+  const int G = gridDim.x;
+  int tau = blockIdx.x;
+  if (tau >= a.tiles) return;
+
+  // slab staging role: patch row r = 64*j + wave*8 + (lane>>3); LDS position p = lane&7 holds source chunk p ^ (r&7)
+  const int sr = wave * 8 + (lane >> 3), sp = lane & 7, sc = sp ^ (sr & 7);
+  const uint32_t pix_bytes = (uint32_t)a.Cin * 2u;
+  const uint32_t st_lds = (uint32_t)(sr * 128 + sp * 16);
+  auto slab_load = [&](const TileGeo& g, int chunk, int j) -> u32x4_t {
+    int pix = g.P0 + 64 * j + sr;
+    pix = pix < a.in_pix ? pix : a.in_pix - 1;
+    return *reinterpret_cast<const u32x4_t*>(a.in + (size_t)((uint32_t)pix * pix_bytes + (uint32_t)(chunk * 128 + sc * 16)));
+  };
+  auto slab_store = [&](int buf, int j, const u32x4_t& v) {
+    *reinterpret_cast<u32x4_t*>(pbuf + buf * PATCHB + j * 8192 + st_lds) = v;
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  // weights, fragment-major: byte offset of (n16, kb, lane) = ((n16*KB + kb)*64 + lane)*16
+  // weights through a buffer descriptor: voffset = lane*16 (constant), everything else is a wave-uniform scalar offset,
+  // so a weight fetch costs no vector ALU work at all
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+  const int lane16 = lane * 16;
+  const int wn_u = __builtin_amdgcn_readfirstlane(wn);
+  auto w_load = [&](const TileGeo& g, int kb, u32x4_t (&f)[4]) {   // one MFMA k-step (32 channels) of this wave's 64 weight rows
+    const int n16 = (g.n0 + wn_u * 64) >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      f[j] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, ((n16 + j) * a.KB + kb) * 1024, 0));
+  };
+  auto kb_of = [&](int c, int t) { return (t * a.Cin + c * 64) >> 5; };
+
+  int nstamp = 0;
+  auto stamp = [&]() {
+    if (a.stamps && wave == 0 && nstamp < 32) {
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      if (lane == 0) a.stamps[blockIdx.x * 32 + nstamp] = t;
+      ++nstamp;
+    }
+  };
+  stamp();
+  TileGeo g = tile_geo(a, tau);
+  // prologue: first slab -> LDS buffer 0, first tap's weights -> registers
+  {
+    u32x4_t tmp[NSLICE];
+#pragma unroll
+    for (int j = 0; j < NSLICE; ++j) tmp[j] = slab_load(g, 0, j);
+#pragma unroll
+    for (int j = 0; j < NSLICE; ++j) slab_store(0, j, tmp[j]);
+  }
+  u32x4_t Wa[4], Wb[4], Xa[4], Xb[4];   // operand fragments of the even / odd k-step of a tap
+  w_load(g, kb_of(0, 0), Wa);
+  __syncthreads();   // tap table + slab 0 visible
+  stamp();
+
+  int pcur = 0;
+  while (true) {
+    int lbase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m = g.m0 + wm * 64 + i * 16 + fr;
+      m = m < a.M_img ? m : a.M_img - 1;
+      lbase[i] = pixbase(a, g.b, m) - g.P0;
+    }
+    const int tau_next = tau + G;
+    const bool has_next = tau_next < a.tiles;
+    TileGeo gn = g;
+    if (has_next) gn = tile_geo(a, tau_next);
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c < a.nchunk; ++c) {
+      const bool last_chunk = c + 1 == a.nchunk;
+      const bool stage_next = !last_chunk || has_next;
+      const TileGeo gs = last_chunk ? gn : g;   // owner of the next slab
+      const int cs = last_chunk ? 0 : c + 1;
+      const char* pb = pbuf + pcur * PATCHB;
+      u32x4_t stg = {0, 0, 0, 0};
+      int sj = 0;          // next slice to fetch; slice sj-1 is in `stg` waiting to be written
+
+      // A fragments of one k-step of tap t: 4 x ds_read_b128 from the slab at the tap's row shift.  The second k-step's
+      // chunk index differs by 4, i.e. its swizzled address is the first one's XOR 64.
+      uint32_t xaddr[4];
+      auto x_addr = [&](int t) {
+        const int toff = taptab[t];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int prow = lbase[i] + toff;
+          xaddr[i] = (uint32_t)(prow * 128 + ((fg ^ (prow & 7)) << 4));
+        }
+      };
+      auto x_load = [&](int kq, u32x4_t (&xf)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const u32x4_t*>(pb + (xaddr[i] ^ (kq ? 64u : 0u)));
+      };
+      auto mma16 = [&](const u32x4_t (&wf)[4], const u32x4_t (&xf)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[j]), __builtin_bit_cast(bf16x8_t, xf[i]), acc[i][j], 0, 0, 0);
+      };
+      // Software pipeline at k-step granularity: while 16 MFMAs of one k-step run, the fragments of the next k-step are
+      // fetched (weights from L2/L1, activations from the LDS slab) into the other register set.
+      x_addr(0);
+      x_load(0, Xa);   // Wa was fetched by the previous slab's last step (or the prologue)
+      for (int t = 0; t < a.ntaps; ++t) {
+        const bool last_tap = t + 1 == a.ntaps;
+        w_load(g, kb_of(c, t) + 1, Wb);
+        x_load(1, Xb);
+        if (stage_next) {
+          if (sj > 0 && sj <= NSLICE) slab_store(pcur ^ 1, sj - 1, stg);
+          if (sj < NSLICE) stg = slab_load(gs, cs, sj);
+          ++sj;
+        }
+        mma16(Wa, Xa);
+        if (!last_tap) { w_load(g, kb_of(c, t + 1), Wa); x_addr(t + 1); x_load(0, Xa); }
+        else if (!last_chunk) w_load(g, kb_of(c + 1, 0), Wa);     // the next slab's activations wait for the barrier
+        else if (has_next) w_load(gn, kb_of(0, 0), Wa);
+        mma16(Wb, Xb);
+      }
+      // flush the slices the taps did not get to (few-tap layers), then hand the buffer over
+      if (stage_next) {
+        while (sj <= NSLICE) {
+          if (sj > 0) slab_store(pcur ^ 1, sj - 1, stg);
+          if (sj < NSLICE) stg = slab_load(gs, cs, sj);
+          ++sj;
+        }
+      }
+      __syncthreads();   // every wave is done with slab `pcur`; slab `pcur^1` is completely written
+      pcur ^= 1;
+      stamp();
+    }
+
+    // ---- epilogue (the next tile's slab is in LDS and its first weights are in flight)
+    bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
+    const bf16_t* mask = reinterpret_cast<const bf16_t*>(a.mask);
+    f32x4_t bq[4];   // bias of this lane's 4 channel quads
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = g.n0 + wn * 64 + j * 16 + fg * 4;
+      bq[j] = (a.bias && n < a.Nst) ? *reinterpret_cast<const f32x4_t*>(a.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool odd = fg & 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = g.m0 + wm * 64 + i * 16 + fr;
+      const bool mok = m < a.M_img;
+      const int mm = mok ? m : a.M_img - 1;
+      const int ho = mm / a.Wo, wo = mm - ho * a.Wo;
+      const int64_t ob = ((int64_t)(g.b * a.out_Hp + ho * a.out_sy + a.out_y0) * a.out_Wp + wo * a.out_sx + a.out_x0) * a.out_C;
+      u32x2_t pk[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[i][j][e] + bq[j][e], a.act);
+        if (mask) {
+          const int n = g.n0 + wn * 64 + j * 16 + fg * 4;
+          if (n < a.Nst) {
+            const int64_t mb = ((int64_t)(g.b * a.mask_Hp + ho * a.out_sy + a.mask_y0) * a.mask_Wp + wo * a.out_sx + a.mask_x0) * a.out_C;
+            const u32x2_t mv = *reinterpret_cast<const u32x2_t*>(mask + mb + n);
+            v[0] *= (bf2f((bf16_t)(mv[0] & 0xffff)) > 0.f ? 1.f : 0.2f); v[1] *= (bf2f((bf16_t)(mv[0] >> 16)) > 0.f ? 1.f : 0.2f);
+            v[2] *= (bf2f((bf16_t)(mv[1] & 0xffff)) > 0.f ? 1.f : 0.2f); v[3] *= (bf2f((bf16_t)(mv[1] >> 16)) > 0.f ? 1.f : 0.2f);
+          }
+        }
+        pk[j][0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        pk[j][1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+      }
+      // lanes 16 apart hold the same pixel and adjacent channel quads: even fg keeps tiles 0 and 2, odd fg keeps 1 and 3;
+      // each sends the quads of the tiles it does not keep -> every lane ends with two 16-byte runs
+      uint32_t sx[4], rx[4];
+      sx[0] = odd ? pk[0][0] : pk[1][0]; sx[1] = odd ? pk[0][1] : pk[1][1];
+      sx[2] = odd ? pk[2][0] : pk[3][0]; sx[3] = odd ? pk[2][1] : pk[3][1];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rx[q] = (uint32_t)__shfl_xor((int)sx[q], 16, 64);
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        u32x4_t st;
+        if (!odd) { st[0] = pk[2 * jp][0]; st[1] = pk[2 * jp][1]; st[2] = rx[2 * jp]; st[3] = rx[2 * jp + 1]; }
+        else      { st[0] = rx[2 * jp]; st[1] = rx[2 * jp + 1]; st[2] = pk[2 * jp + 1][0]; st[3] = pk[2 * jp + 1][1]; }
+        const int nst = g.n0 + wn * 64 + (2 * jp + (odd ? 1 : 0)) * 16 + (fg & 2) * 4;
+        if (mok && nst < a.Nst) *reinterpret_cast<u32x4_t*>(out + ob + nst) = st;
+      }
+    }
+
+    stamp();
+    if (!has_next) break;
+    tau = tau_next;
+    g = gn;
+  }
+}
+
+}  // namespace
+
+// Pure predicate (no device access): does this descriptor qualify for the range-patch kernel?  The planner asks at
+// build time because qualifying calls need the fragment-major weight packing (gan_pack_weight layout 1).
+extern "C" int gan_conv_patch_ok(const gan_conv_desc* d) {
+  static int disabled = -1;
+  if (disabled < 0) { const char* e = getenv("GAN_NO_PATCH"); disabled = (e && atoi(e)) ? 1 : 0; }
+  if (disabled || !d) return 0;
+  if (d->dtype != GAN_BF16 || d->Cin < 64 || d->Cin % 64 != 0 || d->Nw % BN != 0 || d->Nst % 8 != 0 || d->out_C % 8 != 0) return 0;
+  if (d->max_tapoff <= 0 || d->ntaps < 1) return 0;
+  const int M_img = d->Ho * d->Wo;
+  const int maxtap = d->max_tapoff / d->Cin;
+  const int rows = BM < M_img ? BM : M_img;
+  const int wraps = (rows - 1) / d->Wo + 1;
+  const int jump = d->in_Wp * d->in_sy - d->Wo * d->in_sx;
+  const int span = (rows - 1) * d->in_sx + wraps * (jump > 0 ? jump : 0) + maxtap + 1;
+  return span <= RMAX ? 1 : 0;
+}
+
+int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
+  if (!gan_conv_patch_ok(d)) return gan_set_error(-1, "conv: w_layout=1 (fragment-major weights) but the descriptor does not qualify for the range-patch kernel");
+  PatchArgs a;
+  const int M_img = d->Ho * d->Wo;
+  a.in = (const char*)d->in; a.w = (const char*)d->w; a.bias = d->bias; a.out = (char*)d->out; a.mask = (const char*)d->mask; a.tapoff = d->tapoff;
+  a.B = d->B; a.M_img = M_img; a.Wo = d->Wo; a.MT_img = (M_img + BM - 1) / BM; a.NTILES = (d->Nst + BN - 1) / BN;
+  a.tiles = a.B * a.MT_img * a.NTILES;
+  a.Cin = d->Cin; a.nchunk = d->Cin / 64; a.ntaps = d->ntaps; a.KB = d->ntaps * d->Cin / 32;
+  a.w_bytes = d->Nw * d->ntaps * d->Cin * 2;
+  a.in_Hp = d->in_Hp; a.in_Wp = d->in_Wp; a.in_y0 = d->in_y0; a.in_x0 = d->in_x0; a.in_sy = d->in_sy; a.in_sx = d->in_sx;
+  a.in_pix = d->B * d->in_Hp * d->in_Wp;
+  a.out_Hp = d->out_Hp; a.out_Wp = d->out_Wp; a.out_C = d->out_C; a.out_y0 = d->out_y0; a.out_x0 = d->out_x0; a.out_sy = d->out_sy; a.out_sx = d->out_sx;
+  a.Nst = d->Nst; a.act = d->act;
+  a.mask_Hp = d->mask_Hp; a.mask_Wp = d->mask_Wp; a.mask_y0 = d->mask_y0; a.mask_x0 = d->mask_x0;
+  { const char* e = getenv("GAN_PATCH_STAMPS"); a.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+      return gan_set_error(-2, "conv_patch: cannot raise the dynamic LDS limit to %d bytes", LDS_BYTES);
+    attr_set = true;
+  }
+  const int ncu = 256;
+  const int grid = a.tiles < ncu ? a.tiles : ncu;
+  hipLaunchKernelGGL(conv_patch_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
+  if (hipGetLastError() != hipSuccess) return gan_set_error(-2, "conv_patch: launch failed");
+  return 0;
+}

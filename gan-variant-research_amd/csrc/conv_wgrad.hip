@@ -221,7 +221,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, 
 
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int Nw, int ntaps, int Cin, int N_real, int C_real,
-                                   int swap, int I2, int KK, const int32_t* __restrict__ khw) {
+                                   int swap, int I2, int KK, const int32_t* __restrict__ khw, int layout) {
   const int64_t total = (int64_t)Nw * ntaps * Cin;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % Cin);
@@ -230,7 +230,12 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict_
     float v = 0.f;
     const int k = khw[t];
     if (n < N_real && c < C_real && k >= 0) v = src[swap ? ((int64_t)c * I2 + n) * KK + k : ((int64_t)n * I2 + c) * KK + k];
-    st1<T>(dst + i, v);
+    int64_t o = i;
+    if (layout == 1) {
+      const int kk = t * Cin + c, KB = ntaps * Cin / 32;
+      o = ((((int64_t)(n >> 4) * KB + (kk >> 5)) * 64) + ((kk & 31) >> 3) * 16 + (n & 15)) * 8 + (kk & 7);
+    }
+    st1<T>(dst + o, v);
   }
 }
 
@@ -331,12 +336,13 @@ extern "C" int gan_wgrad_reduce(const float* part, int nsplit, int N, int ntaps,
 }
 
 extern "C" int gan_pack_weight(const float* src, void* dst, int dtype, int Nw, int ntaps, int Cin, int N_real, int C_real, int swap,
-                               int I2, int KK, const int32_t* khw, void* stream) {
+                               int I2, int KK, const int32_t* khw, int layout, void* stream) {
   GAN_CHECK(src && dst && khw && N_real <= Nw && C_real <= Cin, "pack_weight: bad arguments");
+  GAN_CHECK(layout == 0 || (layout == 1 && Nw % 16 == 0 && (ntaps * Cin) % 32 == 0), "pack_weight: bad layout %d", layout);
   const int64_t total = (int64_t)Nw * ntaps * Cin;
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   GAN_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pack_weight_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (T*)dst, Nw,
-                                               ntaps, Cin, N_real, C_real, swap, I2, KK, khw);)
+                                               ntaps, Cin, N_real, C_real, swap, I2, KK, khw, layout);)
   GAN_LAUNCH_CHECK();
   return 0;
 }

@@ -273,9 +273,10 @@ class _InferenceRunner:
         self.gpass = self.net.new_pass(B, H, W)
         self.xin = torch.zeros(B, 3, H, W, dtype=torch.float32, device=x.device)
         self.out = torch.zeros(B, 3, H, W, dtype=torch.float32, device=x.device)
+        fwd = self.gpass.fwd_program(self.xin)      # planning allocates the operand copies the repack must refresh
         self.prog = Program("infer")
         self.prog.add(self.net.repack_program())
-        self.prog.add(self.gpass.fwd_program(self.xin))
+        self.prog.add(fwd)
         self.prog.add(ops.view_to_nchw(self.gpass.img, 3, self.out))
 
     def __call__(self, x, layer_ids):
@@ -394,15 +395,10 @@ class CutTrainer:
             pd.add(ops.patch_loss(dp.logits, mode, 0.0, 0.5, self._slot(slot), gl))
             pd.add(dp.bwd_program(gl, wgrad=True, accumulate=(i == 1)))
         self.prog_d_compute = pd
-        self.prog_d_update = Program("D-update")
-        self.prog_d_update.add(self.opt_D.step_op(cfg.get("grad_clip_d", 10.0), gs))
-        self.prog_d_update.add(self.D.repack_program())
 
         # ---- lazy R1 (train_cutpp.py:165-203, 257-263), always fp32 like the reference
-        pr = Program("R1")
+        pr = Program("R1-body")
         rp, c32, dnet = self.d_r1, self.ctx32, self.D32
-        if dnet is not self.D:
-            pr.add(dnet.repack_program())
         pr.add(ops.nchw_to_view(self.photos, 3, rp.x, HALO_ZERO))
         pr.add(rp.fwd_program())
         lg = rp.logits
@@ -432,10 +428,7 @@ class CutTrainer:
                 skip.append([k for k, v in self.opt_D.grads.items() if v is conv.grad_b][0])
             else:
                 pr.add(ops.fill(conv.grad_b, 0.0))
-        self.prog_r1_compute = pr
-        self.prog_r1_update = Program("R1-update")
-        self.prog_r1_update.add(self.opt_D.step_op(cfg.get("grad_clip_d", 10.0), gs, skip=skip))
-        self.prog_r1_update.add(self.D.repack_program())
+        r1_body, r1_skip = pr, skip
 
         # ---- G step (train_cutpp.py:266-308)
         pg = Program("G-step")
@@ -481,6 +474,17 @@ class CutTrainer:
         pi.add(ops.l1_loss(self.p3.img, 3, self.monets, 1.0, self._slot("idw"), self._slot("identity"), g_idt, ctx.scratch("l1_ws", 1024)))
         pi.add(self.p3.bwd_program(g_idt, accumulate=True))
         self.prog_g_identity = pi
+        # ---- optimiser updates and operand-copy refresh: built LAST, when every conv call (hence every weight copy) is planned
+        self.prog_d_update = Program("D-update")
+        self.prog_d_update.add(self.opt_D.step_op(cfg.get("grad_clip_d", 10.0), gs))
+        self.prog_d_update.add(self.D.repack_program())
+        self.prog_r1_compute = Program("R1")
+        if self.D32 is not self.D:
+            self.prog_r1_compute.add(self.D32.repack_program())   # fp32 operand copies are only needed on R1 steps
+        self.prog_r1_compute.add(r1_body)
+        self.prog_r1_update = Program("R1-update")
+        self.prog_r1_update.add(self.opt_D.step_op(cfg.get("grad_clip_d", 10.0), gs, skip=r1_skip))
+        self.prog_r1_update.add(self.D.repack_program())
         self.prog_g_update = Program("G-update")
         self.prog_g_update.add(self.opt_G.step_op(cfg.get("grad_clip_g", 10.0), gs))
         self.prog_g_update.add(self.G.repack_program())

@@ -76,7 +76,7 @@ class ConvCall:
     in_sy: int
     in_sx: int
     tapoff: torch.Tensor
-    w: torch.Tensor
+    w: Optional[torch.Tensor]
     bias: Optional[torch.Tensor]
     out: View
     out_y0: int
@@ -87,6 +87,8 @@ class ConvCall:
     mask: Optional[View] = None
     mask_y0: int = 0
     mask_x0: int = 0
+    max_tapoff: int = 0
+    w_frag: bool = False      # w is the fragment-major copy (range-patch kernel)
 
 
 @dataclass
@@ -190,20 +192,29 @@ class HipOps:
         return C.byref(v.struct())
 
     # ---- convolution family
-    def conv_igemm(self, c: ConvCall) -> Op:
-        self._keep.append(c)
+    def _conv_desc(self, c: ConvCall) -> GanConvDesc:
         d = GanConvDesc()
         d.dtype, d.B, d.Ho, d.Wo, d.Cin, d.ntaps, d.Nw, d.Nst = c.x.dtype, c.B, c.Ho, c.Wo, c.Cin, c.ntaps, c.Nw, c.Nst
         d.in_, d.in_Hp, d.in_Wp, d.in_y0, d.in_x0, d.in_sy, d.in_sx = c.x.ptr(), c.x.Hp, c.x.Wp, c.in_y0, c.in_x0, c.in_sy, c.in_sx
-        d.tapoff, d.w, d.bias = c.tapoff.data_ptr(), c.w.data_ptr(), (c.bias.data_ptr() if c.bias is not None else None)
+        d.tapoff, d.w, d.bias = c.tapoff.data_ptr(), (c.w.data_ptr() if c.w is not None else None), (c.bias.data_ptr() if c.bias is not None else None)
         d.out, d.out_Hp, d.out_Wp, d.out_C = c.out.ptr(), c.out.Hp, c.out.Wp, c.out.C
         d.out_y0, d.out_x0, d.out_sy, d.out_sx, d.act = c.out_y0, c.out_x0, c.out_sy, c.out_sx, c.act
         if c.mask is not None:
             assert c.mask.C == c.out.C and c.mask.dtype == c.out.dtype
             d.mask, d.mask_Hp, d.mask_Wp, d.mask_y0, d.mask_x0 = c.mask.ptr(), c.mask.Hp, c.mask.Wp, c.mask_y0, c.mask_x0
         d.stats = None
+        d.max_tapoff = c.max_tapoff
+        d.w_layout = 1 if c.w_frag else 0
         assert c.out.dtype == c.x.dtype
-        return self._call("gan_conv_igemm", C.byref(d), self._s())
+        return d
+
+    def conv_patch_ok(self, c: ConvCall) -> bool:
+        """True if the range-patch kernel takes this call (then `c.w` must be the fragment-major weight copy)."""
+        return bool(self.lib.gan_conv_patch_ok(C.byref(self._conv_desc(c))))
+
+    def conv_igemm(self, c: ConvCall) -> Op:
+        self._keep.append(c)
+        return self._call("gan_conv_igemm", C.byref(self._conv_desc(c)), self._s())
 
     def conv_wgrad(self, c: WgradCall) -> Op:
         self._keep.append(c)
@@ -220,9 +231,9 @@ class HipOps:
         return self._call("gan_wgrad_reduce", self._p(part), nsplit, N, ntaps, Cx, N_real, C_real, int(swap), I2, KK, self._p(khw),
                           self._p(grad), int(accumulate), self._s())
 
-    def pack_weight(self, src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, swap, I2, KK, khw) -> Op:
+    def pack_weight(self, src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, swap, I2, KK, khw, layout=0) -> Op:
         return self._call("gan_pack_weight", self._p(src), self._p(dst), dtype, Nw, ntaps, Cin, N_real, C_real, int(swap), I2, KK,
-                          self._p(khw), self._s())
+                          self._p(khw), int(layout), self._s())
 
     def bias_grad(self, g: View, N_real, grad, accumulate, ws) -> Op:
         return self._call("gan_bias_grad", self._v(g), N_real, self._p(grad), int(accumulate), self._p(ws), self._s())

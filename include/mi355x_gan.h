@@ -59,6 +59,9 @@ typedef struct gan_conv_desc {
   int32_t mask_Hp, mask_Wp, mask_y0, mask_x0;
   float* stats;                  /* optional fp32 [B][out_C][2]: += per-(b,n) sum and sum of squares of the
                                     pre-activation result (InstanceNorm statistics fused in the epilogue) */
+  int32_t max_tapoff;            /* largest value in tapoff[] (needed by the range-patch kernel's span check) */
+  int32_t w_layout;              /* 0: w is [Nw][ntaps][Cin] (generic kernel); 1: fragment-major [Nw/16][ntaps*Cin/32][64][8]
+                                    for the range-patch kernel (the descriptor must satisfy gan_conv_patch_ok) */
 } gan_conv_desc;
 
 /* Weight-gradient GEMM: part[s][n][t][c] = sum over the rows m of split s of
@@ -85,13 +88,18 @@ int gan_version(void);
  *      (GAN_Variant1/models/generator_resnet_attn.py:33,48,113,125,146-149,160; discriminator_patchgan.py:27,38,45,51;
  *       Basic_GAN/src/models.py:12,16,29,37,50-51,59,81,88,96,103) */
 int gan_conv_igemm(const gan_conv_desc* d, void* stream);
+/* 1 if the descriptor qualifies for the range-patch kernel (bf16, Cin % 64 == 0, Nw % 128 == 0, one tile's pixel span fits
+ * the LDS slab); pure host-side predicate used by the planner to choose the weight layout */
+int gan_conv_patch_ok(const gan_conv_desc* d);
 int gan_conv_wgrad(const gan_wgrad_desc* d, void* stream);
 /* grad[(a*I2 + b)*KK + khw[t]] (+)= sum_s part[s][n][t][c], (a,b) = swap ? (c,n) : (n,c), for n<N_real, c<C_real, khw[t]>=0 */
 int gan_wgrad_reduce(const float* part, int nsplit, int N, int ntaps, int Cx, int N_real, int C_real, int swap, int I2,
                      int KK, const int32_t* khw, float* grad, int accumulate, void* stream);
-/* dst[n][t][c] = src[(a*I2 + b)*KK + khw[t]] (0 where n>=N_real, c>=C_real or khw[t]<0); dst dtype GAN_*  */
+/* dst[n][t][c] = src[(a*I2 + b)*KK + khw[t]] (0 where n>=N_real, c>=C_real or khw[t]<0); dst dtype GAN_*.
+ * layout 0: row-major [Nw][ntaps][Cin]; layout 1: fragment-major, element (n, k=t*Cin+c) at
+ * (((n/16)*(ntaps*Cin/32) + k/32)*64 + ((k%32)/8)*16 + n%16)*8 + k%8 (one MFMA operand fragment = 1 KB contiguous) */
 int gan_pack_weight(const float* src, void* dst, int dtype, int Nw, int ntaps, int Cin, int N_real, int C_real, int swap,
-                    int I2, int KK, const int32_t* khw, void* stream);
+                    int I2, int KK, const int32_t* khw, int layout, void* stream);
 /* bias gradient: grad[n] (+)= sum over logical pixels of g[...,n], n < N_real (column sums of dY) */
 int gan_bias_grad(const gan_view* g, int N_real, float* grad, int accumulate, float* ws, void* stream);
 

@@ -51,8 +51,6 @@ def run_conv_geometry(ctx, geom, dtype, B=2):
     b = (torch.randn(cout) * 0.1).to(ctx.device)
     gw, gb = torch.zeros_like(w), torch.zeros_like(b)
     layer = ConvLayer(ctx, w, b, gw, gb, k, s, p, tr)
-    for op in layer.repack_ops():
-        op()
     x = torch.randn(B, cin, H, H)
     if dtype == BF16:
         x, w_ref = x.bfloat16().float(), w.cpu().bfloat16().float()
@@ -69,7 +67,10 @@ def run_conv_geometry(ctx, geom, dtype, B=2):
     Ho = y_ref.shape[2]
     xin = to_view(ctx, x, max(p, 1), HALO_REFLECT if reflect else HALO_ZERO)
     y = ctx.view(B, Ho, Ho, cpad(cout), 0)
-    for op in layer.fwd(xin, y):
+    fwd_ops = layer.fwd(xin, y)
+    for op in layer.repack_ops():   # operand copies are allocated when a call is planned: plan first, then pack
+        op()
+    for op in fwd_ops:
         op()
     tol = dict(rtol=1e-4, atol=1e-4) if dtype == F32 else dict(rtol=3e-2, atol=6e-2)
     np.testing.assert_allclose(from_view(y, cout).numpy(), y_ref.detach().numpy(), **tol)
@@ -95,6 +96,8 @@ def run_conv_geometry(ctx, geom, dtype, B=2):
         dyv = to_view(ctx, gy, k - 1 - p, HALO_ZERO)
         dx = ctx.view(B, H, H, cpad(cin), 0)
         ops, fold = layer.dgrad(dyv, dx), False
+    for op in layer.repack_ops():
+        op()
     for op in ops:
         op()
     out = ctx.view(B, H, H, cpad(cin), 0)

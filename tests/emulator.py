@@ -70,12 +70,31 @@ class EmuOps:
         self.device = torch.device("cpu")
 
     # ------------------------------------------------------------------ convolution family
+    def conv_patch_ok(self, c):
+        """Statement of gan_conv_patch_ok (csrc/conv_patch.hip)."""
+        if c.x.dtype != 1 or c.Cin < 64 or c.Cin % 64 or c.Nw % 128 or c.Nst % 8 or c.out.C % 8 or c.max_tapoff <= 0:
+            return False
+        m_img = c.Ho * c.Wo
+        rows = min(256, m_img)
+        wraps = (rows - 1) // c.Wo + 1
+        jump = max(0, c.x.Wp * c.in_sy - c.Wo * c.in_sx)
+        return (rows - 1) * c.in_sx + wraps * jump + c.max_tapoff // c.Cin + 1 <= 448
+
+    @staticmethod
+    def _unfrag(wf, Nw, K):
+        """fragment-major [Nw/16][K/32][fg 4][fr 16][8] -> row-major [Nw][K]"""
+        return wf.view(Nw // 16, K // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(Nw, K)
+
     def conv_igemm(self, c):
         def op():
             x = c.x.padded().float()
             Cin, Wp = c.Cin, c.x.Wp
             assert c.x.C == Cin
-            w = c.w.view(c.Nw, c.ntaps, Cin).float()
+            if c.w_frag:
+                assert self.conv_patch_ok(c)
+                w = self._unfrag(c.w.float(), c.Nw, c.ntaps * Cin).view(c.Nw, c.ntaps, Cin)
+            else:
+                w = c.w.view(c.Nw, c.ntaps, Cin).float()
             acc = torch.zeros(c.B, c.Ho, c.Wo, c.Nw)
             toff = c.tapoff.tolist()
             bke = 32 if c.x.dtype == 0 else 64
@@ -142,7 +161,7 @@ class EmuOps:
             g.copy_(new)
         return op
 
-    def pack_weight(self, src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, swap, I2, KK, khw):
+    def pack_weight(self, src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, swap, I2, KK, khw, layout=0):
         def op():
             out = torch.zeros(Nw, ntaps, Cin)
             s = src.reshape(-1).float()
@@ -153,6 +172,9 @@ class EmuOps:
                     continue
                 o = ((c_idx * I2 + n_idx) if swap else (n_idx * I2 + c_idx)) * KK + k
                 out[:N_real, t, :C_real] = s[o]
+            if layout == 1:
+                K = ntaps * Cin
+                out = out.view(Nw // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4)
             dst.view(-1).copy_(out.reshape(-1).to(dst.dtype))
         return op
 

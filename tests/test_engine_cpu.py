@@ -17,6 +17,17 @@ def test_conv_geometry(geom, dtype):
     cases.run_conv_geometry(Ctx(EmuOps(), "cpu", dtype), geom, dtype)
 
 
+@pytest.mark.parametrize("geom", [cases.GEOMS[8], cases.GEOMS[10], cases.GEOMS[13]])
+def test_conv_geometry_fragment_major(geom):
+    """Full-width bf16 layers take the range-patch kernel: fragment-major weight copies, checked through the emulator."""
+    ctx = Ctx(EmuOps(), "cpu", BF16)
+    seen = []
+    orig = ctx.ops.conv_igemm
+    ctx.ops.conv_igemm = lambda c: (seen.append(c.w_frag), orig(c))[1]
+    cases.run_conv_geometry(ctx, geom, BF16)
+    assert any(seen), "no call qualified for the range-patch kernel"
+
+
 def test_module_state_dict_keys_and_init():
     cut_ref.set_seed(42)
     gp, dp = cut_ref.init_generator(), cut_ref.init_discriminator()

@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gan_variant_research_amd import F32, BF16
 from gan_variant_research_amd.runtime import Ctx, HipOps, ConvCall
 dev = torch.device("cuda:0")
