@@ -59,6 +59,7 @@ PROTOTYPES = {
     "gan_in_finalize": (C.c_int, [vp, C.c_int, C.c_int, f32, vp]),
     "gan_in_apply": (C.c_int, [PV, vp, C.c_int, PV, PV, C.c_int, vp]),
     "gan_in_bwd": (C.c_int, [PV, vp, C.c_int, PV, C.c_int, PV, PV, vp, vp]),
+    "gan_in_bwd_bias": (C.c_int, [PV, vp, C.c_int, PV, C.c_int, PV, PV, vp, vp, C.c_int, C.c_int, vp]),
     "gan_fold_add": (C.c_int, [PV, PV, C.c_int, PV, vp]),
     "gan_act_bwd": (C.c_int, [PV, C.c_int, PV, C.c_int, PV, PV, vp]),
     "gan_nchw_to_view": (C.c_int, [vp, C.c_int, PV, C.c_int, vp]),

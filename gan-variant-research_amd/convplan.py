@@ -205,8 +205,8 @@ class ConvLayer:
         return self._phased(self.dgrad_packs, dy, dx, ACT_NONE, None, mask)
 
     # ------------------------------------------------------------------ weight gradient
-    def _nsplit(self, m: int, jtiles: int, ntiles: int) -> int:
-        want = max(1, 1024 // max(1, jtiles * ntiles))
+    def _nsplit(self, m: int, jtiles: int, ntiles: int, ntiles_skinny: bool = False) -> int:
+        want = max(1, (1024 if ntiles_skinny else 512) // max(1, jtiles * ntiles))
         ns = max(1, min(want, m // 512))
         while ns > 1 and (ns - 1) * ((-(-m // ns) + 63) // 64 * 64) >= m:
             ns -= 1
@@ -228,7 +228,7 @@ class ConvLayer:
         ktot = self.kk * cx
         m = g.B * g.H * g.W
         jt, ntl = 16 * epc, (16 if n <= 16 else (128 if ctx.dtype == BF16 else 64))
-        ns = self._nsplit(m, -(-ktot // jt), -(-n // ntl))
+        ns = self._nsplit(m, -(-ktot // jt), -(-n // ntl), n <= 16)
         part = ctx.scratch("wgrad_part", ns * n * ktot)
         key = (xo.Wp, cx)
         tapoff = self._wg_tapoff.get(key)

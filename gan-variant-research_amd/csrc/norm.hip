@@ -235,12 +235,15 @@ __global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const float* __res
 }
 template <typename T>
 __global__ __launch_bounds__(NTHR) void in_bwd_apply_kernel(DView x, const float* __restrict__ stats, int act, DView gy, int fold, DView g2,
-                                                           int has_g2, const float* __restrict__ ws2, DView dx, int nblk) {
+                                                           int has_g2, const float* __restrict__ ws2, DView dx, int nblk,
+                                                           float* __restrict__ bias_part) {
   constexpr int N = Chunk<T>::N;
   Lanes<T> L(x.C);
   const int b = blockIdx.y, HW = x.H * x.W;
   const int per = (HW + nblk - 1) / nblk, p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
-  float mean[N], rstd[N], m1[N], m2[N];
+  float mean[N], rstd[N], m1[N], m2[N], bs[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) bs[e] = 0.f;
 #pragma unroll
   for (int e = 0; e < N; ++e) {
     const int64_t i = (int64_t)b * x.C + L.cl * N + e;
@@ -252,8 +255,40 @@ __global__ __launch_bounds__(NTHR) void in_bwd_apply_kernel(DView x, const float
     float g[N], xh[N];
     in_bwd_g<T>(x, mean, rstd, act, gy, fold, g2, has_g2, b, yy, xx, L.cl * N, g, xh);
 #pragma unroll
-    for (int e = 0; e < N; ++e) g[e] = rstd[e] * (g[e] - m1[e] - xh[e] * m2[e]);
+    for (int e = 0; e < N; ++e) { g[e] = rstd[e] * (g[e] - m1[e] - xh[e] * m2[e]); bs[e] += g[e]; }
     Chunk<T>::store(dp + dx.pix(b, yy, xx) + L.cl * N, g);
+  }
+  if (bias_part) {   // column sums of dx = gradient of the conv bias in front of this norm: partial per block
+    __shared__ float sh[NTHR * 8];
+#pragma unroll
+    for (int e = 0; e < N; ++e) sh[threadIdx.x * N + e] = bs[e];
+    __syncthreads();
+    if (L.rl == 0) {
+      for (int r = 1; r < L.RL; ++r)
+#pragma unroll
+        for (int e = 0; e < N; ++e) bs[e] += sh[(r * L.CL + L.cl) * N + e];
+      float* o = bias_part + (int64_t)(b * nblk + blockIdx.x) * x.C + L.cl * N;
+#pragma unroll
+      for (int e = 0; e < N; ++e) o[e] = bs[e];
+    }
+  }
+}
+// out[seg][c] (+)= sum over this segment's blocks of part[blk][c]; gridDim.y segments (two-level reduction: many partials,
+// few channels -> the first level spreads the partial list over gridDim.y blocks per 32 channels)
+__global__ __launch_bounds__(256) void bias_part_finalize_kernel(const float* __restrict__ part, int nparts, int C, int N_real, float* __restrict__ out,
+                                                                int out_stride, int accumulate) {
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), k0 = threadIdx.x >> 5;
+  const int per = (nparts + gridDim.y - 1) / gridDim.y, p0 = blockIdx.y * per, p1 = min(nparts, p0 + per);
+  float s = 0.f;
+  if (c < C)
+    for (int k = p0 + k0; k < p1; k += 8) s += part[(int64_t)k * C + c];
+  __shared__ float sh[256];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (k0 == 0 && c < N_real) {
+    for (int k = 1; k < 8; ++k) s += sh[k * 32 + (threadIdx.x & 31)];
+    float* o = out + (int64_t)blockIdx.y * out_stride + c;
+    *o = accumulate ? *o + s : s;
   }
 }
 
@@ -422,8 +457,24 @@ extern "C" int gan_in_apply(const gan_view* x, const float* stats, int act, cons
 }
 
 // ws: fp32, >= B*MAXCH*C*2 + B*C*2 floats
+static int in_bwd_impl(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2, const gan_view* dx,
+                       float* ws, float* bias_grad, int bias_n, int bias_acc, void* stream);
+
 extern "C" int gan_in_bwd(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2,
                           const gan_view* dx, float* ws, void* stream) {
+  return in_bwd_impl(x, stats, act, gy, fold, g2, dx, ws, nullptr, 0, 0, stream);
+}
+
+// same, and additionally bias_grad[n] (+)= sum over pixels of dx[...,n], n < bias_n (the conv bias in front of the norm).
+// ws: fp32 >= B*96*C*2 + B*C*2 + (B*1024 + 32)*C floats
+extern "C" int gan_in_bwd_bias(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2,
+                               const gan_view* dx, float* ws, float* bias_grad, int bias_n, int bias_accumulate, void* stream) {
+  GAN_CHECK(bias_grad && bias_n > 0 && bias_n <= x->C, "in_bwd_bias: bad bias arguments");
+  return in_bwd_impl(x, stats, act, gy, fold, g2, dx, ws, bias_grad, bias_n, bias_accumulate, stream);
+}
+
+static int in_bwd_impl(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2, const gan_view* dx,
+                       float* ws, float* bias_grad, int bias_n, int bias_acc, void* stream) {
   VCHK(x, "in_bwd.x"); VCHK(gy, "in_bwd.gy"); VCHK(dx, "in_bwd.dx");
   if (check_lanes(x, "in_bwd")) return -1;
   SAME_SHAPE(x, gy, "in_bwd(x,gy)"); SAME_SHAPE(x, dx, "in_bwd(x,dx)");
@@ -439,7 +490,19 @@ extern "C" int gan_in_bwd(const gan_view* x, const float* stats, int act, const 
   GAN_DISPATCH_DTYPE(x->dtype,
     hipLaunchKernelGGL((in_bwd_partial_kernel<T>), dim3(nch, x->B), dim3(NTHR), 0, s, vx, stats, act, vg, fold, v2, g2 ? 1 : 0, nch, ws);
     hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3((BC + 31) / 32), dim3(256), 0, s, ws, nch, x->C, BC, HW, ws2);
-    hipLaunchKernelGGL((in_bwd_apply_kernel<T>), dim3(nblk, x->B), dim3(NTHR), 0, s, vx, stats, act, vg, fold, v2, g2 ? 1 : 0, ws2, vd, nblk);)
+    hipLaunchKernelGGL((in_bwd_apply_kernel<T>), dim3(nblk, x->B), dim3(NTHR), 0, s, vx, stats, act, vg, fold, v2, g2 ? 1 : 0, ws2, vd, nblk,
+                       bias_grad ? ws2 + (int64_t)BC * 2 : nullptr);)
+  if (bias_grad) {
+    float* part = ws2 + (int64_t)BC * 2;
+    const int nparts = x->B * nblk;
+    if (nparts > 64) {   // two levels: 32 segments -> scratch behind the partials, then the final 32 -> grad
+      float* seg = part + (int64_t)nparts * x->C;
+      hipLaunchKernelGGL(bias_part_finalize_kernel, dim3((x->C + 31) / 32, 32), dim3(256), 0, s, part, nparts, x->C, x->C, seg, x->C, 0);
+      hipLaunchKernelGGL(bias_part_finalize_kernel, dim3((x->C + 31) / 32, 1), dim3(256), 0, s, seg, 32, x->C, bias_n, bias_grad, 0, bias_acc);
+    } else {
+      hipLaunchKernelGGL(bias_part_finalize_kernel, dim3((x->C + 31) / 32, 1), dim3(256), 0, s, part, nparts, x->C, bias_n, bias_grad, 0, bias_acc);
+    }
+  }
   GAN_LAUNCH_CHECK();
   return 0;
 }

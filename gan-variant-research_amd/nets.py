@@ -60,7 +60,7 @@ class _Net:
         return v
 
     def in_ws(self, B, C) -> torch.Tensor:
-        return self.ctx.scratch("in_ws", B * IN_WS_CHUNKS * C * 2 + B * C * 2)
+        return self.ctx.scratch("in_ws", B * IN_WS_CHUNKS * C * 2 + B * C * 2 + (B * 1024 + 32) * C)
 
 
 class GeneratorNet(_Net):
@@ -183,8 +183,12 @@ class GPass:
             if i in hooks:
                 prog.add(hooks[i](gv))
 
-        def inbwd(raw, stats, act, gy, fold, dx):
-            prog.add(ops.in_bwd(raw, stats, act, gy, fold, None, dx, net.in_ws(B, raw.C)))
+        def inbwd(raw, stats, act, gy, fold, dx, conv=None):
+            """InstanceNorm backward; with `conv`, its bias gradient (column sums of dx) comes out of the same pass."""
+            if conv is not None and conv.grad_b is not None:
+                prog.add(ops.in_bwd_bias(raw, stats, act, gy, fold, None, dx, net.in_ws(B, raw.C), conv.grad_b, conv.cout, acc))
+            else:
+                prog.add(ops.in_bwd(raw, stats, act, gy, fold, None, dx, net.in_ws(B, raw.C)))
 
         i = self.last
         g_cur: Optional[View] = None   # gradient wrt acts[i]
@@ -207,8 +211,8 @@ class GPass:
             hook(i, g_cur)
             a_in = self.acts[i - 1]
             dy = net.gbuf(f"dy_up{j}", B, self.raw[i].H, self.raw[i].W, self.raw[i].C, 1)
-            inbwd(self.raw[i], self.stats[i], ACT_RELU, g_cur, g_fold, dy)
-            prog.add(net.c_up[j].wgrad(a_in, dy, acc))
+            inbwd(self.raw[i], self.stats[i], ACT_RELU, g_cur, g_fold, dy, net.c_up[j])
+            prog.add(net.c_up[j].wgrad(a_in, dy, acc, bias_too=False))
             g_cur = net.gbuf(f"g_act{a_in.H}x{a_in.C}", B, a_in.H, a_in.W, a_in.C, 0)
             prog.add(net.c_up[j].dgrad(dy, g_cur))
             g_fold = False
@@ -222,13 +226,13 @@ class GPass:
             sa, sb = self.stats[i]
             c4, h4, w4 = ra.C, ra.H, ra.W
             dyb = net.gbuf("dy_blk", B, h4, w4, c4, 2)
-            inbwd(rb, sb, ACT_NONE, g_cur, False, dyb)
-            prog.add(cb.wgrad(self.mid[k], dyb, acc))
+            inbwd(rb, sb, ACT_NONE, g_cur, False, dyb, cb)
+            prog.add(cb.wgrad(self.mid[k], dyb, acc, bias_too=False))
             g_mid = net.gbuf("g_blk_p", B, h4, w4, c4, 1)
             prog.add(cb.dgrad(dyb, g_mid, padded_domain=True))
             dya = net.gbuf("dy_blk", B, h4, w4, c4, 2)
-            inbwd(ra, sa, ACT_RELU, g_mid, True, dya)
-            prog.add(ca.wgrad(self.acts[i - 1], dya, acc))
+            inbwd(ra, sa, ACT_RELU, g_mid, True, dya, ca)
+            prog.add(ca.wgrad(self.acts[i - 1], dya, acc, bias_too=False))
             g_in_p = net.gbuf("g_blk_p", B, h4, w4, c4, 1)
             prog.add(ca.dgrad(dya, g_in_p, padded_domain=True))
             g_next = net.gbuf(f"g_res{k % 2}", B, h4, w4, c4, 0)
@@ -240,15 +244,15 @@ class GPass:
             hook(i, g_cur)
             a_in = self.acts[i - 1]
             dy = net.gbuf(f"dy_down{i}", B, self.raw[i].H, self.raw[i].W, self.raw[i].C, 1)
-            inbwd(self.raw[i], self.stats[i], ACT_RELU, g_cur, False, dy)
-            prog.add(net.c_down[i - 1].wgrad(a_in, dy, acc))
+            inbwd(self.raw[i], self.stats[i], ACT_RELU, g_cur, False, dy, net.c_down[i - 1])
+            prog.add(net.c_down[i - 1].wgrad(a_in, dy, acc, bias_too=False))
             g_cur = net.gbuf(f"g_act{a_in.H}x{a_in.C}", B, a_in.H, a_in.W, a_in.C, 0)
             prog.add(net.c_down[i - 1].dgrad(dy, g_cur))
             i -= 1
         hook(0, g_cur)
         dy0 = net.gbuf("dy_init", B, H, W, g, 6 if need_input_grad else 0)
-        inbwd(self.raw[0], self.stats[0], ACT_RELU, g_cur, False, dy0)
-        prog.add(net.c_init.wgrad(self.x0, dy0, acc))
+        inbwd(self.raw[0], self.stats[0], ACT_RELU, g_cur, False, dy0, net.c_init)
+        prog.add(net.c_init.wgrad(self.x0, dy0, acc, bias_too=False))
         self.g_input = None
         if need_input_grad:
             self.g_input = net.gbuf("g_x0", B, H, W, self.x0.C, 3)   # padded domain: consumer folds

@@ -248,6 +248,10 @@ class HipOps:
     def in_bwd(self, x: View, stats, act, gy: View, fold, g2: Optional[View], dx: View, ws) -> Op:
         return self._call("gan_in_bwd", self._v(x), self._p(stats), act, self._v(gy), int(fold), self._v(g2), self._v(dx), self._p(ws), self._s())
 
+    def in_bwd_bias(self, x: View, stats, act, gy: View, fold, g2: Optional[View], dx: View, ws, bias_grad, bias_n, accumulate) -> Op:
+        return self._call("gan_in_bwd_bias", self._v(x), self._p(stats), act, self._v(gy), int(fold), self._v(g2), self._v(dx), self._p(ws),
+                          self._p(bias_grad), bias_n, int(accumulate), self._s())
+
     def fold_add(self, a: Optional[View], b: View, fold, out: View) -> Op:
         return self._call("gan_fold_add", self._v(a), self._v(b), int(fold), self._v(out), self._s())
 

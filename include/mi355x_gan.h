@@ -116,6 +116,10 @@ int gan_in_apply(const gan_view* x, const float* stats, int act, const gan_view*
  * ws: fp32 >= B*96*C*2 + B*C*2 floats (gan_in_stats: B*96*C*2). */
 int gan_in_bwd(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2,
                const gan_view* dx, float* ws, void* stream);
+/* gan_in_bwd that also produces the gradient of the convolution bias in front of the norm (column sums of dx) in the same
+ * pass: bias_grad[n] (+)= sum_pixels dx[..,n], n < bias_n.  ws: fp32 >= B*96*C*2 + B*C*2 + (B*1024+32)*C floats. */
+int gan_in_bwd_bias(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2,
+                    const gan_view* dx, float* ws, float* bias_grad, int bias_n, int bias_accumulate, void* stream);
 /* out = a + fold(b): gradient of a residual block input (skip path + reflect-padded conv path) */
 int gan_fold_add(const gan_view* a, const gan_view* b, int fold, const gan_view* out, void* stream);
 /* dx = g * act'(y) (tanh: 1-y^2, lrelu: y>0?1:0.2), g optionally folded; written to the interior of dx */

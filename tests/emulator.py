@@ -224,6 +224,15 @@ class EmuOps:
             _store(dx, st[..., 1] * (g - m1 - xh * m2))
         return op
 
+    def in_bwd_bias(self, x, stats, act, gy, fold, g2, dx, ws, bias_grad, bias_n, accumulate):
+        inner = self.in_bwd(x, stats, act, gy, fold, g2, dx, ws)
+
+        def op():
+            inner()
+            s = dx.nhwc().float().sum((0, 1, 2))[:bias_n]
+            bias_grad.copy_(bias_grad + s if accumulate else s)
+        return op
+
     def fold_add(self, a, b, fold, out):
         def op():
             v = _fold(b, fold)
