@@ -104,7 +104,11 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--fp32", action="store_true", help="parity mode (exact fp32 MFMA) instead of bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["cut", "basic"], default="cut",
+                    help="cut: BASELINE.json configs[2] (the metric's config); basic: configs[1], Basic_GAN CycleGAN 64x64 batch 256")
     args = ap.parse_args()
+    if args.workload == "basic":
+        return main_basic(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -177,6 +181,39 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_basic(args):
+    """BASELINE.json configs[1]: Basic_GAN (CycleGAN) inner loop at 64x64, bf16, batch 256 on one GPU (a parity / secondary
+    bench line; the headline metric is the CUT line)."""
+    from gan_variant_research_amd import basic as BG
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    B = 256 if args.batch == 16 else args.batch
+    S = 64 if args.size == 256 else args.size
+    cfg = {"training": {"amp": not args.fp32, "seed": 0}, "optim": {"lr_g": 2e-4, "lr_d": 2e-4, "betas": [0.5, 0.999]},
+           "loss": {"gan": "lsgan", "lambda_cycle": 10.0, "lambda_identity": 0.5},
+           "model": {"ngf": 64, "ndf": 64, "n_blocks": 9, "spectral_norm_d": False}}
+    torch.manual_seed(0)
+    tr = BG.CycleGANTrainer(*BG.build_models(cfg, dev), cfg, B, S, device=dev, amp=not args.fp32)
+    g = torch.Generator().manual_seed(1234)
+    a = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)
+    b = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)
+    last = None
+    for _ in range(args.warmup):
+        last = tr.train_iteration(a, b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = tr.train_iteration(a, b)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"metric": "images/sec (G+D train step) Basic_GAN CycleGAN 64x64", "value": round(B * args.steps / dt, 3), "unit": "images/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
+           "config": {"workload": f"Basic_GAN CycleGAN (2 ResNet-9 G + 2 PatchGAN D with InstanceNorm), {S}x{S}, batch {B} (BASELINE.json configs[1])",
+                      "global_batch": B, "parallelism": "dp1"}, "last_losses": last}
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -165,3 +165,40 @@ def run_cut_steps(device, ops, use_aug, amp=False, S=32, B=2, nsteps=2, tol0=2e-
     img = tr.generated().cpu()
     ref_img = cut_ref.generator_forward(g_before, photos).detach()
     return tr, img, ref_img
+
+
+def basic_config():
+    """Basic_GAN/configs/baseline.yaml (the keys the loop reads)."""
+    return {"training": {"amp": False, "seed": 0}, "optim": {"lr_g": 2e-4, "lr_d": 2e-4, "betas": [0.5, 0.999]},
+            "loss": {"gan": "lsgan", "lambda_cycle": 10.0, "lambda_identity": 0.5},
+            "model": {"ngf": 64, "ndf": 64, "n_blocks": 9, "spectral_norm_d": False}}
+
+
+def run_basic_iterations(device, ops, amp=False, S=32, B=2, niter=2, tol0=2e-4, tol1=2e-3):
+    """CycleGAN inner loop (Basic_GAN/src/train.py:66-122) on the engine vs the oracle."""
+    from gan_variant_research_amd import basic as BG
+    from oracle import basic_ref
+    cfg = basic_config()
+    cfg["training"]["amp"] = amp
+    torch.manual_seed(0)
+    mods = BG.build_models(cfg, "cpu")
+    torch.manual_seed(0)
+    gab, gba = basic_ref.init_generator(), basic_ref.init_generator()
+    da, db = basic_ref.init_discriminator(), basic_ref.init_discriminator()
+    for m, ref in zip(mods, (gab, gba, da, db)):
+        sd = m.state_dict()
+        assert list(sd) == list(ref)
+        for k in ref:
+            assert torch.equal(sd[k], ref[k]), k
+    tr = BG.CycleGANTrainer(*[m.to(device) for m in mods], cfg, B, S, device=device, amp=amp, ops=ops)
+    both = {**{"ab." + k: v for k, v in gab.items()}, **{"ba." + k: v for k, v in gba.items()}}
+    og, oa, ob = cut_ref.AdamState(both), cut_ref.AdamState(da), cut_ref.AdamState(db)
+    g = torch.Generator().manual_seed(77)
+    a = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    b = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    for it in range(niter):
+        ref = basic_ref.train_iteration(a, b, gab, gba, da, db, og, oa, ob)
+        got = tr.train_iteration(a.to(device), b.to(device))
+        for k in ref:
+            np.testing.assert_allclose(got[k], ref[k], rtol=tol0 if it == 0 else tol1, atol=1e-5, err_msg=f"it{it} {k}")
+    return tr

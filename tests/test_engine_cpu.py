@@ -45,3 +45,8 @@ def test_module_state_dict_keys_and_init():
 def test_cut_train_step_matches_oracle(use_aug):
     torch.set_num_threads(4)
     cases.run_cut_steps("cpu", EmuOps(), use_aug)
+
+
+def test_basic_gan_iterations_match_oracle():
+    torch.set_num_threads(4)
+    cases.run_basic_iterations("cpu", EmuOps())

@@ -213,3 +213,12 @@ def test_generator_module_forward_and_features(golden):
     for i, f in enumerate(feats):
         assert list(f.shape) == list(g[f"feat{i}.shape"])
         np.testing.assert_allclose(f[:, :8, :4, :4].cpu().numpy(), g[f"feat{i}.slice"], rtol=1e-3, atol=1e-3)
+
+
+def test_basic_gan_iterations_fp32_vs_oracle():
+    """Basic_GAN CycleGAN inner loop (Basic_GAN/src/train.py:66-122), fp32 parity mode, 64x64, two iterations."""
+    cases.run_basic_iterations(DEV, HipOps(torch.device(DEV)), amp=False, S=64, B=2, tol0=1e-3, tol1=2e-3)
+
+
+def test_basic_gan_iterations_bf16_vs_oracle():
+    cases.run_basic_iterations(DEV, HipOps(torch.device(DEV)), amp=True, S=64, B=2, niter=1, tol0=4e-2)
