@@ -118,7 +118,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
-    if world > 1:
+    force_dist = bool(int(os.environ.get("GAN_FORCE_DIST", "0")))   # exercise the RCCL path even with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
@@ -129,6 +130,8 @@ def main():
     C.set_seed(42)                                       # identical replicas on every rank
     gen, disc = C.build_models(cfg, dev)
     tr = C.CutTrainer(gen, disc, cfg, args.batch, args.size, device=dev, amp=not args.fp32, world_size=world, process_group=pg)
+    if force_dist:
+        tr.force_allreduce = True
     g = torch.Generator().manual_seed(1234 + rank)
     photos = (torch.rand(args.batch, 3, args.size, args.size, generator=g) * 2 - 1).to(dev)
     monets = (torch.rand(args.batch, 3, args.size, args.size, generator=g) * 2 - 1).to(dev)

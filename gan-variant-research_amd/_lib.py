@@ -36,7 +36,7 @@ class GanWgradDesc(C.Structure):
                 ("x", vp), ("x_Hp", i32), ("x_Wp", i32), ("x_y0", i32), ("x_x0", i32), ("x_sy", i32), ("x_sx", i32),
                 ("tapoff", vp), ("g", vp),
                 ("g_Hp", i32), ("g_Wp", i32), ("g_C", i32), ("g_y0", i32), ("g_x0", i32), ("g_sy", i32), ("g_sx", i32),
-                ("part", vp)]
+                ("part", vp), ("max_tapoff", i32), ("variant", i32)]
 
 
 class GanAdamTensor(C.Structure):
@@ -51,6 +51,7 @@ PROTOTYPES = {
     "gan_version": (C.c_int, []),
     "gan_conv_igemm": (C.c_int, [PC, vp]),
     "gan_conv_wgrad": (C.c_int, [PW, vp]),
+    "gan_wgrad_patch_splits": (C.c_int, [PW]),
     "gan_wgrad_reduce": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "gan_conv_patch_ok": (C.c_int, [PC]),
     "gan_pack_weight": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),

@@ -228,15 +228,21 @@ class ConvLayer:
         ktot = self.kk * cx
         m = g.B * g.H * g.W
         jt, ntl = 16 * epc, (16 if n <= 16 else (128 if ctx.dtype == BF16 else 64))
-        ns = self._nsplit(m, -(-ktot // jt), -(-n // ntl), n <= 16)
-        part = ctx.scratch("wgrad_part", ns * n * ktot)
         key = (xo.Wp, cx)
         tapoff = self._wg_tapoff.get(key)
         if tapoff is None:
             tapoff = ctx.i32([(kh * xo.Wp + kw) * cx for kh in range(k) for kw in range(k)])
             self._wg_tapoff[key] = tapoff
-        out = [ops.conv_wgrad(WgradCall(g.B, g.H, g.W, cx, self.kk, n, ns, xo, xo.halo - p, xo.halo - p, stride, stride, tapoff, g,
-                                        g.halo, g.halo, 1, 1, part)),
+        call = WgradCall(g.B, g.H, g.W, cx, self.kk, n, 1, xo, xo.halo - p, xo.halo - p, stride, stride, tapoff, g, g.halo, g.halo, 1, 1, None,
+                         max_tapoff=((k - 1) * xo.Wp + (k - 1)) * cx)
+        spi = ops.wgrad_patch_splits(call)
+        if spi > 0:      # range-patch kernel: splits never cross an image
+            call.nsplit, call.variant = g.B * spi, 1
+        else:
+            call.nsplit = self._nsplit(m, -(-ktot // jt), -(-n // ntl), n <= 16)
+        ns = call.nsplit
+        call.part = part = ctx.scratch("wgrad_part", ns * n * ktot)
+        out = [ops.conv_wgrad(call),
                ops.wgrad_reduce(part, ns, n, self.kk, cx, n_real, c_real, False, i2, self.kk, self.wg_khw, self.grad_w, accumulate)]
         if bias_too and self.grad_b is not None:
             out.append(ops.bias_grad(dy, self.cout, self.grad_b, accumulate, ctx.scratch("bias_ws", 256 * max(dy.C, 256))))

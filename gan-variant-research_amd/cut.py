@@ -514,7 +514,7 @@ class CutTrainer:
             dst.copy_(ids.to(torch.int32))
 
     def _allreduce(self, opt: FusedAdam):
-        if self.world_size > 1:
+        if self.world_size > 1 or getattr(self, "force_allreduce", False):
             import torch.distributed as dist
             dist.all_reduce(opt.flat_g, group=self.pg)   # RCCL over xGMI; sum, the optimiser divides by world_size
 

@@ -112,7 +112,9 @@ class WgradCall:
     g_x0: int
     g_sy: int
     g_sx: int
-    part: torch.Tensor
+    part: Optional[torch.Tensor]
+    max_tapoff: int = 0
+    variant: int = 0          # 1: range-patch kernel (nsplit = B * splits per image)
 
 
 Op = Callable[[], None]
@@ -216,16 +218,25 @@ class HipOps:
         self._keep.append(c)
         return self._call("gan_conv_igemm", C.byref(self._conv_desc(c)), self._s())
 
-    def conv_wgrad(self, c: WgradCall) -> Op:
-        self._keep.append(c)
+    def _wgrad_desc(self, c: WgradCall) -> GanWgradDesc:
         d = GanWgradDesc()
         d.dtype, d.B, d.Ho, d.Wo, d.Cx, d.ntaps, d.N, d.nsplit = c.x.dtype, c.B, c.Ho, c.Wo, c.Cx, c.ntaps, c.N, c.nsplit
         d.x, d.x_Hp, d.x_Wp, d.x_y0, d.x_x0, d.x_sy, d.x_sx = c.x.ptr(), c.x.Hp, c.x.Wp, c.x_y0, c.x_x0, c.x_sy, c.x_sx
         d.tapoff, d.g = c.tapoff.data_ptr(), c.g.ptr()
         d.g_Hp, d.g_Wp, d.g_C, d.g_y0, d.g_x0, d.g_sy, d.g_sx = c.g.Hp, c.g.Wp, c.g.C, c.g_y0, c.g_x0, c.g_sy, c.g_sx
-        d.part = c.part.data_ptr()
-        assert c.g.dtype == c.x.dtype and c.part.numel() >= c.nsplit * c.N * c.ntaps * c.Cx
-        return self._call("gan_conv_wgrad", C.byref(d), self._s())
+        d.part = c.part.data_ptr() if c.part is not None else None
+        d.max_tapoff, d.variant = c.max_tapoff, c.variant
+        assert c.g.dtype == c.x.dtype
+        return d
+
+    def wgrad_patch_splits(self, c: WgradCall) -> int:
+        """Splits per image the range-patch weight-gradient kernel wants for this call (0: not eligible)."""
+        return int(self.lib.gan_wgrad_patch_splits(C.byref(self._wgrad_desc(c))))
+
+    def conv_wgrad(self, c: WgradCall) -> Op:
+        self._keep.append(c)
+        assert c.part.numel() >= c.nsplit * c.N * c.ntaps * c.Cx
+        return self._call("gan_conv_wgrad", C.byref(self._wgrad_desc(c)), self._s())
 
     def wgrad_reduce(self, part, nsplit, N, ntaps, Cx, N_real, C_real, swap, I2, KK, khw, grad, accumulate) -> Op:
         return self._call("gan_wgrad_reduce", self._p(part), nsplit, N, ntaps, Cx, N_real, C_real, int(swap), I2, KK, self._p(khw),

@@ -123,6 +123,22 @@ class EmuOps:
             out[:, oy[:, None], ox[None, :], :c.Nst] = v.to(out.dtype)
         return op
 
+    def wgrad_patch_splits(self, c):
+        """Statement of gan_wgrad_patch_splits (csrc/wgrad_patch.hip); the variant is opt-in (GAN_WPATCH=1)."""
+        import os
+        if not int(os.environ.get("GAN_WPATCH", "0")):
+            return 0
+        if c.x.dtype != 1 or c.ntaps != 9 or c.Cx % 64 or c.N % 128 or c.N != c.g.C or c.max_tapoff <= 0:
+            return 0
+        if (c.x_sy, c.x_sx, c.g_sy, c.g_sx) != (1, 1, 1, 1) or c.Ho * c.Wo < 128:
+            return 0
+        wraps = 127 // c.Wo + 1
+        if 127 + wraps * max(0, c.x.Wp - c.Wo) + c.max_tapoff // c.Cx + 1 > 288:
+            return 0
+        bps = (c.N // 128) * (c.Cx // 64)
+        spi = (256 + c.B * bps - 1) // (c.B * bps)
+        return max(1, min(spi, max(1, c.Ho * c.Wo // 256)))
+
     def conv_wgrad(self, c):
         def op():
             x = c.x.padded().float()
