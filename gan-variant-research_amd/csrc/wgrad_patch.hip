@@ -1,17 +1,20 @@
-// "Range-patch" weight gradient for stride-1 windows with <= 9 taps on narrow maps (the 18 residual 3x3 256->256
+// "Range-patch" weight gradient for stride-1 3x3 windows on maps whose width divides 128 (the 18 residual 3x3 256->256
 // convolutions: 54 of the 76 weight-gradient launches of a CUT step).
 //
 //   part[s][n][t][c] = sum over the pixels m of split s of  g[m][n] * x[pix(m) + tapoff[t]][c]
 //
-// Same lesson as conv_patch.hip: the generic kernel (conv_wgrad.hip) spends its time in one barrier per 64-pixel K-step
-// and re-stages x once per tap.  Here a block owns an output tile of 128 n x 64 c x ALL taps and walks its pixel range in
-// stages of 128 pixels: the g tile (128 x 128 n) and ONE contiguous pixel range of x (128 + window span pixels x 64 c)
-// are staged by LDS-DMA, then every tap reads its x fragments from that same range at a shifted row -- one barrier per
-// 144 MFMA per wave.  Both operands are reduction-major in memory, so fragments come from ds_read_b64_tr_b16; the MFMA
-// k index is permuted (k = 16h + 4*lanegroup + q, identically for both operands) so that the eight rows a half-wave
-// reads are CONSECUTIVE pixels: with x rows stored at a 160-byte stride (and the g tile's 32-byte pieces XOR-ed by row & 7) the
-// transposed reads are bank-conflict free at ANY tap shift, and a tap costs one address add per read.  4 waves (one per SIMD, 512-register budget) = 2 (n) x 2 (c); a
-// wave owns 4 n-tiles x 2 c-tiles x 9 taps = 72 accumulator tiles and prefetches x fragments four taps ahead of their MFMAs.
+// Same lesson as conv_patch.hip: the generic kernel (conv_wgrad.hip) pays one block-wide barrier per 64-pixel K-step and
+// re-stages x once per tap.  Here a block owns an output tile of 128 n x 64 c x ALL 9 taps and walks its pixel range in
+// stages of 128 pixels (= 128/Wo whole image rows): the g tile (128 pixels x 128 n) and the x window (128/Wo + 2 image rows
+// x 64 c) are staged once by LDS-DMA and every tap reads its x fragments from that window at a shifted position -- one
+// barrier per 144 MFMA per wave.  Both operands are reduction-major in memory, so fragments come from ds_read_b64_tr_b16.
+//  * The MFMA k index is permuted (k = 16h + 4*lanegroup + q, identically for both operands) so that the eight rows a
+//    half-wave reads are CONSECUTIVE pixels; the 32-byte piece index is XOR-ed by row bits (g: row&7, x: (row>>1)&3), which
+//    makes the transposed reads bank-conflict free at ANY pixel shift.
+//  * The x window is stored as a 2-D image whose row pitch is padded to a multiple of 8 pixels: the vertical part of a tap
+//    offset then never changes the swizzle bits and becomes an immediate offset of the ds_read; only the three horizontal
+//    shifts need their own (precomputed) swizzled address -> ~1 vector ALU op per transposed read.
+//  * 8 waves = 2 (n) x 4 (c); a wave owns 4 n-tiles x 1 c-tile x 9 taps = 36 accumulator tiles (144 registers).
 #include <stdlib.h>
 #include "common.h"
 
@@ -19,17 +22,16 @@ namespace {
 
 constexpr int KM = 128;            // pixels per stage
 constexpr int NB = 128, CB = 64;   // output tile: g channels x x channels (x all taps)
-constexpr int RX = 288;            // x pixel rows per stage buffer (>= KM + window span)
-constexpr int XROW = 160;          // x rows padded 128 -> 160 bytes: 8 consecutive rows at one 32-byte column hit 8 distinct bank groups
-constexpr int GT_BYTES = KM * 256, XP_BYTES = RX * XROW, STAGE_BYTES = GT_BYTES + XP_BYTES;
-constexpr int LDS_BYTES = 2 * STAGE_BYTES + 256;
-constexpr int MAXT = 9;
+constexpr int RX = 320;            // x window rows (pixels incl. pitch padding) per stage buffer
+constexpr int GT_BYTES = KM * 256, XP_BYTES = RX * 128, STAGE_BYTES = GT_BYTES + XP_BYTES;
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+constexpr int NT = 9;
 
 struct WpArgs {
-  const char* x; const char* g; const int32_t* tapoff; float* part;
-  int B, HoWo, Wo, spi, per;       // spi: splits per image, per: pixels per split (multiple of KM)
-  int Cx, ntaps, N;
-  int x_Hp, x_Wp, x_y0, x_x0, x_pix;
+  const char* x; const char* g; float* part;
+  int B, HoWo, Wo, lgWo, spi, per;   // spi: splits per image, per: pixels per split (multiple of KM)
+  int Cx, N, pitch, nrows;           // pitch: padded window row pitch (pixels, multiple of 8); nrows: image rows per window
+  int x_Hp, x_Wp, x_y0, x_x0;        // x_y0/x_x0: position of tap (0,0) of output pixel (0,0) inside the padded image
   int g_Hp, g_Wp, g_C, g_y0, g_x0;
   int NBLK, CBLK;
 };
@@ -38,12 +40,8 @@ __device__ __forceinline__ void glds16q(const char* gbase, uint32_t goff, char* 
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + goff),
                                    (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
-// g tile (256-byte rows): a half-wave's transposed read touches 8 consecutive rows at one 32-byte column -> XOR the 32-byte
-// piece index (= 16-byte chunk index >> 1) with row & 7
-__device__ __forceinline__ int swz_g(int row) { return (row & 7) << 1; }
 
-template <int NT>
-__global__ __launch_bounds__(256) void wgrad_patch_kernel(WpArgs a) {
+__global__ __launch_bounds__(512) void wgrad_patch_kernel(WpArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -56,154 +54,130 @@ __global__ __launch_bounds__(256) void wgrad_patch_kernel(WpArgs a) {
   const int nstage = (m_end - m_begin + KM - 1) / KM;
   const int n0 = nb * NB, c0 = cb * CB;
 
-  // tap offsets as wave-uniform scalars, in bytes of the padded x image
-  int toffb[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) toffb[t] = __builtin_amdgcn_readfirstlane(a.tapoff[t] / a.Cx) * XROW;
-
-  auto pix_x = [&](int m) { const int ho = m / a.Wo, wo = m - ho * a.Wo; return (b * a.x_Hp + ho + a.x_y0) * a.x_Wp + wo + a.x_x0; };
-  auto pix_g = [&](int m) { const int ho = m / a.Wo, wo = m - ho * a.Wo; return (b * a.g_Hp + ho + a.g_y0) * a.g_Wp + wo + a.g_x0; };
-
-  // ---- staging roles
-  // g tile by LDS-DMA: row gr + 16*i (i<8), LDS position gp (16-byte chunk of the 256-byte row) holds source chunk gp ^ swz_g(row)
+  // ---- staging roles (LDS-DMA, lane-linear images, XOR applied on the SOURCE chunk)
+  // g tile: 128 rows x 256 B; row gr + 32*i (i<4); position gp holds source chunk gp ^ ((row & 7) << 1)
   const int gr = tid >> 4, gp = tid & 15;
-  const uint32_t gsrc0 = (uint32_t)((n0 + ((gp ^ swz_g(gr)) << 3)) * 2), gsrc1 = (uint32_t)((n0 + ((gp ^ swz_g(gr + 16)) << 3)) * 2);
-  (void)gsrc1;   // rows gr+16*i: (row & 7) == (gr & 7) for every i, so one source chunk serves all eight rows
+  const uint32_t gsrc = (uint32_t)((n0 + ((gp ^ ((gr & 7) << 1)) << 3)) * 2);
+  // x window: RX rows x 128 B; row xr + 64*i (i<5); position xp holds source chunk with piece (xp>>1) ^ ((row>>1)&3)
+  const int xr = tid >> 3, xp = tid & 7;
+  const uint32_t xsrc = (uint32_t)((c0 + ((((xp >> 1) ^ ((xr >> 1) & 3)) << 1 | (xp & 1)) << 3)) * 2);
   const uint32_t x_pixb = (uint32_t)a.Cx * 2u, g_pixb = (uint32_t)a.g_C * 2u;
-  // x range through registers into the padded image: row xr + 32*i (i<9), 16-byte chunk xp
-  const int xr = tid >> 3, xp = tid & 7;   // 32 rows per pass
-  const uint32_t xsrc = (uint32_t)((c0 + xp * 8) * 2);
 
-  auto stage_g = [&](int st, int buf) {
+  auto stage = [&](int st, int buf) {
     char* gt = lds + buf * STAGE_BYTES;
-    const int m0 = m_begin + st * KM;
+    char* xw = gt + GT_BYTES;
+    const int m0 = m_begin + st * KM, ho0 = m0 >> a.lgWo;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int m = m0 + gr + 16 * i;
+    for (int i = 0; i < 4; ++i) {
+      int m = m0 + gr + 32 * i;
       m = m < a.HoWo ? m : a.HoWo - 1;   // rows past the split end are zeroed after landing
-      glds16q(a.g, (uint32_t)pix_g(m) * g_pixb + gsrc0, gt + wave * 1024 + i * 4096);
+      const int ho = m >> a.lgWo, wo = m & (a.Wo - 1);
+      glds16q(a.g, (uint32_t)((b * a.g_Hp + ho + a.g_y0) * a.g_Wp + wo + a.g_x0) * g_pixb + gsrc, gt + wave * 1024 + i * 8192);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int row = xr + 64 * i;                      // window row = image row wr, column wcol
+      if (row < a.nrows * a.pitch) {
+        const int wr = row / a.pitch, wcol = row - wr * a.pitch;
+        int iy = ho0 + wr + a.x_y0, ix = wcol + a.x_x0;   // pitch padding and rows past the image read a valid (unused) pixel
+        iy = iy < a.x_Hp ? iy : a.x_Hp - 1;
+        ix = ix < a.x_Wp ? ix : a.x_Wp - 1;
+        glds16q(a.x, (uint32_t)((b * a.x_Hp + iy) * a.x_Wp + ix) * x_pixb + xsrc, xw + wave * 1024 + i * 8192);
+      }
     }
   };
-  constexpr int XI = RX / 32;   // 9 rows per thread
-  auto x_fetch = [&](int P0, int i0, int cnt, u32x4_t (&v)[XI]) {
-#pragma unroll
-    for (int i = 0; i < XI; ++i)
-      if (i >= i0 && i < i0 + cnt) {
-        int pix = P0 + xr + 32 * i;
-        pix = pix < a.x_pix ? pix : a.x_pix - 1;
-        v[i] = *reinterpret_cast<const u32x4_t*>(a.x + (size_t)((uint32_t)pix * x_pixb + xsrc));
-      }
-  };
-  auto x_commit = [&](int buf, int i0, int cnt, const u32x4_t (&v)[XI]) {
-    char* xpb = lds + buf * STAGE_BYTES + GT_BYTES;
-#pragma unroll
-    for (int i = 0; i < XI; ++i)
-      if (i >= i0 && i < i0 + cnt) *reinterpret_cast<u32x4_t*>(xpb + (xr + 32 * i) * XROW + xp * 16) = v[i];
-  };
 
-  const int wn = wave >> 1, wc = wave & 1;
+  const int wn = wave >> 2, wc = wave & 3;
   const int fr = lane & 15, fg = lane >> 4, q = fr >> 2, p4 = fr & 3;
-  // transposed-read geometry: instruction h of k-step ks reads, for lane group fg, pixel rows ks*32 + 16h + 4fg + q
-  uint32_t gcolx[4];   // swizzle-ready g column offsets (chunk bits and intra-chunk bits)
+  // transposed-read geometry: instruction h of k-step ks reads, for lane group fg, pixels ks*32 + 16h + 4fg + q
+  uint32_t gcol[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) gcolx[i] = (uint32_t)(((wn * 4 + i) * 16 + p4 * 4) * 2);
-  const uint32_t xcol = (uint32_t)((wc * 32 + p4 * 4) * 2);   // first of this wave's two c-tiles; the second is +32 bytes
+  for (int i = 0; i < 4; ++i) gcol[i] = (uint32_t)(((wn * 4 + i) * 16 + p4 * 4) * 2);
+  const uint32_t xcol = (uint32_t)((wc * 16 + p4 * 4) * 2);
+  const uint32_t rowb = (uint32_t)(a.pitch * 128);   // bytes per window image row: a multiple of 1024, never touches the swizzle bits
+  // Per-lane base addresses (k-step 0, h = 0).  Every other (k-step, h) adds a wave-uniform byte offset: 16h + 32ks is a
+  // multiple of 8 pixels (swizzle bits unchanged) and, for Wo >= 16, never carries into the lane's 4fg+q part.
+  const int kl = 4 * fg + q;
+  uint32_t gbase[4], xbase[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) gbase[i] = (uint32_t)(kl * 256) + (gcol[i] ^ (uint32_t)((kl & 7) << 5));
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    const int r = kl + dx;
+    xbase[dx] = (uint32_t)(r * 128) + (xcol ^ (uint32_t)((r & 6) << 4));
+  }
 
-  f32x4_t acc[4][2][NT];
+  f32x4_t acc[4][NT];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[i][j][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) acc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  u32x4_t nx[XI];
-  {   // prologue: stage 0
-    x_fetch(pix_x(m_begin), 0, XI, nx);
-    stage_g(0, 0);
-    x_commit(0, 0, XI, nx);
-  }
+  stage(0, 0);
   for (int st = 0; st < nstage; ++st) {
-    __syncthreads();   // stage st is complete in LDS (LDS-DMA drained, x rows written); everyone is done with the other buffer
+    __syncthreads();   // stage st landed (LDS-DMA drained + barrier); everyone is done with the other buffer
     char* gt = lds + (st & 1) * STAGE_BYTES;
-    const char* xpb = gt + GT_BYTES;
+    const char* xw = gt + GT_BYTES;
     const int m0 = m_begin + st * KM;
     if (m0 + KM > m_end) {   // tail: pixels past the split end must not contribute -> zero their g rows
-      for (int c = tid; c < KM * 16; c += 256)
+      for (int c = tid; c < KM * 16; c += 512)
         if (m0 + (c >> 4) >= m_end) *reinterpret_cast<u32x4_t*>(gt + c * 16) = u32x4_t{0, 0, 0, 0};
       __syncthreads();
     }
-    const bool more = st + 1 < nstage;
-    const int Pn = more ? pix_x(m_begin + (st + 1) * KM) : 0;
-    if (more) { stage_g(st + 1, (st + 1) & 1); x_fetch(Pn, 0, XI, nx); }   // lands while this stage computes; written at k-step 2
-
-    // this lane's first pixel of the stage: (ho, wo) once, then 16-pixel steps without divisions
-    const int P0 = pix_x(m0);
-    int m = m0 + 4 * fg + q;
-    int ho = m / a.Wo, wo = m - ho * a.Wo;
+    if (st + 1 < nstage) stage(st + 1, (st + 1) & 1);
 #pragma unroll
     for (int ks = 0; ks < KM / 32; ++ks) {
-      uint32_t xa[2];   // byte address of this lane's x row for h = 0 / 1 (tap 0)
+      // keep the seven base addresses opaque so that the 72 derived addresses are recomputed (1 add each), not hoisted and spilled
+      asm volatile("" : "+v"(gbase[0]), "+v"(gbase[1]), "+v"(gbase[2]), "+v"(gbase[3]), "+v"(xbase[0]), "+v"(xbase[1]), "+v"(xbase[2]));
       s16x4_t gf[4][2];
+      uint32_t xh[2][3];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int hoc = ho < a.HoWo / a.Wo ? ho : a.HoWo / a.Wo - 1;   // clamp rows past the image (their g rows are zero)
-        const int pix = (b * a.x_Hp + hoc + a.x_y0) * a.x_Wp + wo + a.x_x0;
-        xa[h] = (uint32_t)((pix - P0) * XROW) + xcol;
-        const int row = ks * 32 + 16 * h + 4 * fg + q;
-        const uint32_t rb = (uint32_t)(row * 256), sw = (uint32_t)(swz_g(row) << 4);
+        const int ku = ks * 32 + 16 * h;                                                    // wave-uniform part of the pixel index
+        const uint32_t goff = (uint32_t)(ku * 256);
+        const uint32_t xoff = (uint32_t)(((ku >> a.lgWo) * a.pitch + (ku & (a.Wo - 1))) * 128);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          gf[i][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(gt + rb + (gcolx[i] ^ sw)));
-        wo += 16;
-        if (wo >= a.Wo) { wo -= a.Wo; ++ho; }
-        if (wo >= a.Wo) { wo -= a.Wo; ++ho; }   // maps narrower than 16 pixels are not routed here (Wo >= 8 checked on the host)
+          gf[i][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(gt + gbase[i] + goff));
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) xh[h][dx] = xbase[dx] + xoff;
       }
       bf16x8_t av[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         av[i] = bf16x8_t{gf[i][0][0], gf[i][0][1], gf[i][0][2], gf[i][0][3], gf[i][1][0], gf[i][1][1], gf[i][1][2], gf[i][1][3]};
-      // taps: a ring of x fragments (2 c-tiles each), read RING-1 taps ahead of the MFMAs that consume them
-      constexpr int RING = 5;
-      s16x4_t xf[RING][2][2];
+      // 9 taps: a 3-deep ring of x fragments, read two taps ahead of their MFMAs; tap t = (dy, dx) = (t / 3, t % 3)
+      s16x4_t xf[3][2];
       auto x_read = [&](int t) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int h = 0; h < 2; ++h)
-            xf[t % RING][j][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4_t*)(xpb + xa[h] + (uint32_t)(toffb[t] + j * 32)));
+        for (int h = 0; h < 2; ++h)
+          xf[t % 3][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(xw + xh[h][t % 3] + (uint32_t)(t / 3) * rowb));
       };
-#pragma unroll
-      for (int t = 0; t < RING - 1 && t < NT; ++t) x_read(t);
+      x_read(0);
+      x_read(1);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t + RING - 1 < NT) x_read(t + RING - 1);
+        if (t + 2 < NT) x_read(t + 2);
+        const bf16x8_t bv = {xf[t % 3][0][0], xf[t % 3][0][1], xf[t % 3][0][2], xf[t % 3][0][3],
+                             xf[t % 3][1][0], xf[t % 3][1][1], xf[t % 3][1][2], xf[t % 3][1][3]};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const s16x4_t(&f)[2] = xf[t % RING][j];
-          const bf16x8_t bv = {f[0][0], f[0][1], f[0][2], f[0][3], f[1][0], f[1][1], f[1][2], f[1][3]};
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv, acc[i][j][t], 0, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv, acc[i][t], 0, 0, 0);
       }
-      if (more && ks == 2) x_commit((st + 1) & 1, 0, XI, nx);
     }
   }
 
   // D[row = n (fg*4+e)][col = c (fr)]
-  float* part = a.part + (int64_t)sp * a.N * a.ntaps * a.Cx;
+  float* part = a.part + (int64_t)sp * a.N * NT * a.Cx;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int n = n0 + (wn * 4 + i) * 16 + fg * 4 + e;
-          part[((int64_t)n * a.ntaps + t) * a.Cx + c0 + (wc * 2 + j) * 16 + fr] = acc[i][j][t][e];
-        }
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + (wn * 4 + i) * 16 + fg * 4 + e;
+        part[((int64_t)n * NT + t) * a.Cx + c0 + wc * 16 + fr] = acc[i][t][e];
+      }
 }
 
 }  // namespace
@@ -211,19 +185,17 @@ __global__ __launch_bounds__(256) void wgrad_patch_kernel(WpArgs a) {
 // splits per image the range-patch weight-gradient kernel wants for this problem (0 = descriptor does not qualify).
 // The planner sizes `part` for B * spi slabs and sets nsplit = B * spi, variant = 1.
 extern "C" int gan_wgrad_patch_splits(const gan_wgrad_desc* d) {
-  // EXPERIMENTAL (round 1): correct (parity-tested) but slower than the generic kernel because hipcc spills accumulators in
-  // the MFMA loop; opt-in with GAN_WPATCH=1 until the register allocation is fixed.
-  static int enabled = -1;
-  if (enabled < 0) { const char* e = getenv("GAN_WPATCH"); enabled = (e && atoi(e)) ? 1 : 0; }
-  if (!enabled || !d) return 0;
-  if (d->dtype != GAN_BF16 || d->ntaps != MAXT || d->Cx % CB != 0 || d->N % NB != 0 || d->N != d->g_C) return 0;
-  if (d->x_sy != 1 || d->x_sx != 1 || d->g_sy != 1 || d->g_sx != 1 || d->max_tapoff <= 0) return 0;
+  static int disabled = -1;
+  if (disabled < 0) { const char* e = getenv("GAN_NO_WPATCH"); disabled = (e && atoi(e)) ? 1 : 0; }
+  if (disabled || !d) return 0;
+  if (d->dtype != GAN_BF16 || d->ntaps != NT || d->Cx % CB != 0 || d->N % NB != 0 || d->N != d->g_C) return 0;
+  if (d->x_sy != 1 || d->x_sx != 1 || d->g_sy != 1 || d->g_sx != 1) return 0;
+  // 3x3 window in row-major tap order over a map whose width is a power of two dividing the stage
+  if (d->Wo < 16 || (d->Wo & (d->Wo - 1)) != 0 || KM % d->Wo != 0 || d->max_tapoff != (2 * d->x_Wp + 2) * d->Cx) return 0;
   const int HoWo = d->Ho * d->Wo;
-  if (HoWo < KM || d->Wo < 8) return 0;
-  const int wraps = (KM - 1) / d->Wo + 1;
-  const int jump = d->x_Wp - d->Wo;
-  const int span = (KM - 1) + wraps * (jump > 0 ? jump : 0) + d->max_tapoff / d->Cx + 1;
-  if (span > RX) return 0;
+  if (HoWo < KM) return 0;
+  const int pitch = (d->Wo + 2 + 7) / 8 * 8, nrows = KM / d->Wo + 2;
+  if (nrows * pitch > RX) return 0;
   const int blocks_per_split = (d->N / NB) * (d->Cx / CB);
   int spi = (256 + d->B * blocks_per_split - 1) / (d->B * blocks_per_split);   // ~one block per CU
   const int max_spi = HoWo / (2 * KM) > 0 ? HoWo / (2 * KM) : 1;
@@ -236,23 +208,23 @@ int gan_wgrad_patch_launch(const gan_wgrad_desc* d, hipStream_t s) {
   const int spi_want = gan_wgrad_patch_splits(d);
   GAN_CHECK(spi_want > 0 && d->nsplit % d->B == 0, "wgrad: variant=1 but the descriptor does not qualify for the range-patch kernel");
   WpArgs a;
-  a.x = (const char*)d->x; a.g = (const char*)d->g; a.tapoff = d->tapoff; a.part = d->part;
-  a.B = d->B; a.HoWo = d->Ho * d->Wo; a.Wo = d->Wo; a.spi = d->nsplit / d->B;
+  a.x = (const char*)d->x; a.g = (const char*)d->g; a.part = d->part;
+  a.B = d->B; a.HoWo = d->Ho * d->Wo; a.Wo = d->Wo; a.lgWo = __builtin_ctz(d->Wo); a.spi = d->nsplit / d->B;
   int per = (a.HoWo + a.spi - 1) / a.spi;
   per = (per + KM - 1) / KM * KM;
   a.per = per;
   GAN_CHECK((a.spi - 1) * per < a.HoWo, "wgrad_patch: nsplit=%d leaves empty splits", d->nsplit);
-  a.Cx = d->Cx; a.ntaps = d->ntaps; a.N = d->N;
-  a.x_Hp = d->x_Hp; a.x_Wp = d->x_Wp; a.x_y0 = d->x_y0; a.x_x0 = d->x_x0; a.x_pix = d->B * d->x_Hp * d->x_Wp;
+  a.Cx = d->Cx; a.N = d->N; a.pitch = (d->Wo + 2 + 7) / 8 * 8; a.nrows = KM / d->Wo + 2;
+  a.x_Hp = d->x_Hp; a.x_Wp = d->x_Wp; a.x_y0 = d->x_y0; a.x_x0 = d->x_x0;
   a.g_Hp = d->g_Hp; a.g_Wp = d->g_Wp; a.g_C = d->g_C; a.g_y0 = d->g_y0; a.g_x0 = d->g_x0;
   a.NBLK = d->N / NB; a.CBLK = d->Cx / CB;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)wgrad_patch_kernel<MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)wgrad_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return gan_set_error(-2, "wgrad_patch: cannot raise the dynamic LDS limit to %d bytes", LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(wgrad_patch_kernel<MAXT>, dim3(a.NBLK * a.CBLK * d->nsplit), dim3(256), LDS_BYTES, s, a);
+  hipLaunchKernelGGL(wgrad_patch_kernel, dim3(a.NBLK * a.CBLK * d->nsplit), dim3(512), LDS_BYTES, s, a);
   if (hipGetLastError() != hipSuccess) return gan_set_error(-2, "wgrad_patch: launch failed");
   return 0;
 }

@@ -124,16 +124,14 @@ class EmuOps:
         return op
 
     def wgrad_patch_splits(self, c):
-        """Statement of gan_wgrad_patch_splits (csrc/wgrad_patch.hip); the variant is opt-in (GAN_WPATCH=1)."""
-        import os
-        if not int(os.environ.get("GAN_WPATCH", "0")):
-            return 0
-        if c.x.dtype != 1 or c.ntaps != 9 or c.Cx % 64 or c.N % 128 or c.N != c.g.C or c.max_tapoff <= 0:
+        """Statement of gan_wgrad_patch_splits (csrc/wgrad_patch.hip)."""
+        if c.x.dtype != 1 or c.ntaps != 9 or c.Cx % 64 or c.N % 128 or c.N != c.g.C:
             return 0
         if (c.x_sy, c.x_sx, c.g_sy, c.g_sx) != (1, 1, 1, 1) or c.Ho * c.Wo < 128:
             return 0
-        wraps = 127 // c.Wo + 1
-        if 127 + wraps * max(0, c.x.Wp - c.Wo) + c.max_tapoff // c.Cx + 1 > 288:
+        if c.Wo < 16 or c.Wo & (c.Wo - 1) or 128 % c.Wo or c.max_tapoff != (2 * c.x.Wp + 2) * c.Cx:
+            return 0
+        if (128 // c.Wo + 2) * ((c.Wo + 2 + 7) // 8 * 8) > 320:
             return 0
         bps = (c.N // 128) * (c.Cx // 64)
         spi = (256 + c.B * bps - 1) // (c.B * bps)
