@@ -19,6 +19,7 @@
 //  * all global loads are plain VGPR loads (no LDS-DMA), so hipcc's counted s_waitcnt vmcnt(N) keeps the prefetch in flight;
 //  * the epilogue pairs lanes 16 apart (same pixel, adjacent channel quads) and writes 16-byte stores.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
     if (a.stamps && wave == 0 && nstamp < 32) {
       unsigned long long t;
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-      if (lane == 0) a.stamps[blockIdx.x * 32 + nstamp] = t;
+      if (lane == 0) ((unsigned long long*)((uintptr_t)a.stamps & ~(uintptr_t)1))[blockIdx.x * 32 + nstamp] = t;
       ++nstamp;
     }
   };
@@ -204,57 +205,71 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
       stamp();
     }
 
-    // ---- epilogue (the next tile's slab is in LDS and its first weights are in flight)
-    bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
-    const bf16_t* mask = reinterpret_cast<const bf16_t*>(a.mask);
-    f32x4_t bq[4];   // bias of this lane's 4 channel quads
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = g.n0 + wn * 64 + j * 16 + fg * 4;
-      bq[j] = (a.bias && n < a.Nst) ? *reinterpret_cast<const f32x4_t*>(a.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
-    const bool odd = fg & 1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = g.m0 + wm * 64 + i * 16 + fr;
-      const bool mok = m < a.M_img;
-      const int mm = mok ? m : a.M_img - 1;
-      const int ho = mm / a.Wo, wo = mm - ho * a.Wo;
-      const int64_t ob = ((int64_t)(g.b * a.out_Hp + ho * a.out_sy + a.out_y0) * a.out_Wp + wo * a.out_sx + a.out_x0) * a.out_C;
-      u32x2_t pk[4];
+    // ---- epilogue (the next tile's slab is in LDS and its first weights are in flight).  Specialised on the activation at
+    // compile time: with a run-time switch per value the 64 results per lane made this phase VALU-bound (8.4k cycles).
+    auto epilogue = [&](auto act_tag, auto mask_tag) {
+      constexpr int ACT = decltype(act_tag)::value;
+      constexpr bool MASK = decltype(mask_tag)::value;
+      bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
+      const bf16_t* mask = reinterpret_cast<const bf16_t*>(a.mask);
+      f32x4_t bq[4];   // bias of this lane's 4 channel quads
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float v[4];
+        const int n = g.n0 + wn * 64 + j * 16 + fg * 4;
+        bq[j] = (a.bias && n < a.Nst) ? *reinterpret_cast<const f32x4_t*>(a.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+      const bool odd = fg & 1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[i][j][e] + bq[j][e], a.act);
-        if (mask) {
-          const int n = g.n0 + wn * 64 + j * 16 + fg * 4;
-          if (n < a.Nst) {
-            const int64_t mb = ((int64_t)(g.b * a.mask_Hp + ho * a.out_sy + a.mask_y0) * a.mask_Wp + wo * a.out_sx + a.mask_x0) * a.out_C;
-            const u32x2_t mv = *reinterpret_cast<const u32x2_t*>(mask + mb + n);
-            v[0] *= (bf2f((bf16_t)(mv[0] & 0xffff)) > 0.f ? 1.f : 0.2f); v[1] *= (bf2f((bf16_t)(mv[0] >> 16)) > 0.f ? 1.f : 0.2f);
-            v[2] *= (bf2f((bf16_t)(mv[1] & 0xffff)) > 0.f ? 1.f : 0.2f); v[3] *= (bf2f((bf16_t)(mv[1] >> 16)) > 0.f ? 1.f : 0.2f);
+      for (int i = 0; i < 4; ++i) {
+        const int m = g.m0 + wm * 64 + i * 16 + fr;
+        const bool mok = m < a.M_img;
+        const int mm = mok ? m : a.M_img - 1;
+        const int ho = mm / a.Wo, wo = mm - ho * a.Wo;
+        const int64_t ob = ((int64_t)(g.b * a.out_Hp + ho * a.out_sy + a.out_y0) * a.out_Wp + wo * a.out_sx + a.out_x0) * a.out_C;
+        u32x2_t pk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = acc[i][j][e] + bq[j][e];
+            v[e] = ACT == GAN_ACT_RELU ? fmaxf(t, 0.f) : ACT == GAN_ACT_LRELU ? (t > 0.f ? t : 0.2f * t) : ACT == GAN_ACT_TANH ? tanhf(t) : t;
           }
+          if (MASK) {
+            const int n = g.n0 + wn * 64 + j * 16 + fg * 4;
+            if (n < a.Nst) {
+              const int64_t mb = ((int64_t)(g.b * a.mask_Hp + ho * a.out_sy + a.mask_y0) * a.mask_Wp + wo * a.out_sx + a.mask_x0) * a.out_C;
+              const u32x2_t mv = *reinterpret_cast<const u32x2_t*>(mask + mb + n);
+              v[0] *= (bf2f((bf16_t)(mv[0] & 0xffff)) > 0.f ? 1.f : 0.2f); v[1] *= (bf2f((bf16_t)(mv[0] >> 16)) > 0.f ? 1.f : 0.2f);
+              v[2] *= (bf2f((bf16_t)(mv[1] & 0xffff)) > 0.f ? 1.f : 0.2f); v[3] *= (bf2f((bf16_t)(mv[1] >> 16)) > 0.f ? 1.f : 0.2f);
+            }
+          }
+          pk[j][0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          pk[j][1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
         }
-        pk[j][0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        pk[j][1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-      }
-      // lanes 16 apart hold the same pixel and adjacent channel quads: even fg keeps tiles 0 and 2, odd fg keeps 1 and 3;
-      // each sends the quads of the tiles it does not keep -> every lane ends with two 16-byte runs
-      uint32_t sx[4], rx[4];
-      sx[0] = odd ? pk[0][0] : pk[1][0]; sx[1] = odd ? pk[0][1] : pk[1][1];
-      sx[2] = odd ? pk[2][0] : pk[3][0]; sx[3] = odd ? pk[2][1] : pk[3][1];
+        // lanes 16 apart hold the same pixel and adjacent channel quads: even fg keeps tiles 0 and 2, odd fg keeps 1 and 3;
+        // each sends the quads of the tiles it does not keep -> every lane ends with two 16-byte runs
+        uint32_t sx[4], rx[4];
+        sx[0] = odd ? pk[0][0] : pk[1][0]; sx[1] = odd ? pk[0][1] : pk[1][1];
+        sx[2] = odd ? pk[2][0] : pk[3][0]; sx[3] = odd ? pk[2][1] : pk[3][1];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) rx[q] = (uint32_t)__shfl_xor((int)sx[q], 16, 64);
+        for (int q = 0; q < 4; ++q) rx[q] = (uint32_t)__shfl_xor((int)sx[q], 16, 64);
 #pragma unroll
-      for (int jp = 0; jp < 2; ++jp) {
-        u32x4_t st;
-        if (!odd) { st[0] = pk[2 * jp][0]; st[1] = pk[2 * jp][1]; st[2] = rx[2 * jp]; st[3] = rx[2 * jp + 1]; }
-        else      { st[0] = rx[2 * jp]; st[1] = rx[2 * jp + 1]; st[2] = pk[2 * jp + 1][0]; st[3] = pk[2 * jp + 1][1]; }
-        const int nst = g.n0 + wn * 64 + (2 * jp + (odd ? 1 : 0)) * 16 + (fg & 2) * 4;
-        if (mok && nst < a.Nst) *reinterpret_cast<u32x4_t*>(out + ob + nst) = st;
+        for (int jp = 0; jp < 2; ++jp) {
+          u32x4_t st;
+          if (!odd) { st[0] = pk[2 * jp][0]; st[1] = pk[2 * jp][1]; st[2] = rx[2 * jp]; st[3] = rx[2 * jp + 1]; }
+          else      { st[0] = rx[2 * jp]; st[1] = rx[2 * jp + 1]; st[2] = pk[2 * jp + 1][0]; st[3] = pk[2 * jp + 1][1]; }
+          const int nst = g.n0 + wn * 64 + (2 * jp + (odd ? 1 : 0)) * 16 + (fg & 2) * 4;
+          if (mok && nst < a.Nst) *reinterpret_cast<u32x4_t*>(out + ob + nst) = st;
+        }
       }
-    }
+    };
+    using std::integral_constant;
+    if (a.mask) epilogue(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, true>{});   // LeakyReLU' masks only follow plain dgrads
+    else if (a.act == GAN_ACT_NONE) epilogue(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, false>{});
+    else if (a.act == GAN_ACT_LRELU) epilogue(integral_constant<int, GAN_ACT_LRELU>{}, integral_constant<bool, false>{});
+    else if (a.act == GAN_ACT_RELU) epilogue(integral_constant<int, GAN_ACT_RELU>{}, integral_constant<bool, false>{});
+    else epilogue(integral_constant<int, GAN_ACT_TANH>{}, integral_constant<bool, false>{});
 
     stamp();
     if (!has_next) break;
@@ -271,6 +286,7 @@ extern "C" int gan_conv_patch_ok(const gan_conv_desc* d) {
   static int disabled = -1;
   if (disabled < 0) { const char* e = getenv("GAN_NO_PATCH"); disabled = (e && atoi(e)) ? 1 : 0; }
   if (disabled || !d) return 0;
+  if (d->mask && d->act != GAN_ACT_NONE) return 0;   // the masked epilogue is specialised for act = none
   if (d->dtype != GAN_BF16 || d->Cin < 64 || d->Cin % 64 != 0 || d->Nw % BN != 0 || d->Nst % 8 != 0 || d->out_C % 8 != 0) return 0;
   if (d->max_tapoff <= 0 || d->ntaps < 1) return 0;
   const int M_img = d->Ho * d->Wo;

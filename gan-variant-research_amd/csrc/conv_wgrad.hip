@@ -201,21 +201,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int N, int ntaps, int Cx, int N_real, int C_real,
-                                    int swap, int I2, int KK, const int32_t* __restrict__ khw, float* __restrict__ grad, int accumulate) {
-  const int64_t total = (int64_t)N_real * ntaps * C_real;
+// One thread sums 4 consecutive channels c of one (n, t) over all slabs with 16-byte loads (the slabs are the traffic:
+// nsplit x the gradient), then scatters the 4 results into the reference's OIHW / IOHW layout.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int N, int ntaps, int Cx, int N_real, int C_real,
+                                                          int swap, int I2, int KK, const int32_t* __restrict__ khw, float* __restrict__ grad,
+                                                          int accumulate) {
+  const int c4n = Cx >> 2;
+  const int64_t total = (int64_t)N_real * ntaps * c4n;
   const int64_t slab = (int64_t)N * ntaps * Cx;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C_real);
-    const int t = (int)((i / C_real) % ntaps);
-    const int n = (int)(i / ((int64_t)C_real * ntaps));
+    const int c = (int)(i % c4n) * 4;
+    const int t = (int)((i / c4n) % ntaps);
+    const int n = (int)(i / ((int64_t)c4n * ntaps));
     const int k = khw[t];
-    if (k < 0) continue;
-    float s = 0.f;
+    if (k < 0 || c >= C_real) continue;
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
     const float* p = part + ((int64_t)n * ntaps + t) * Cx + c;
-    for (int sp = 0; sp < nsplit; ++sp) s += p[sp * slab];
-    const int64_t o = swap ? ((int64_t)c * I2 + n) * KK + k : ((int64_t)n * I2 + c) * KK + k;
-    grad[o] = accumulate ? grad[o] + s : s;
+    for (int sp = 0; sp < nsplit; ++sp) s += *reinterpret_cast<const f32x4_t*>(p + sp * slab);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (c + e >= C_real) break;
+      const int64_t o = swap ? ((int64_t)(c + e) * I2 + n) * KK + k : ((int64_t)n * I2 + c + e) * KK + k;
+      grad[o] = accumulate ? grad[o] + s[e] : s[e];
+    }
   }
 }
 
@@ -330,8 +338,9 @@ extern "C" int gan_conv_wgrad(const gan_wgrad_desc* d, void* stream) {
 extern "C" int gan_wgrad_reduce(const float* part, int nsplit, int N, int ntaps, int Cx, int N_real, int C_real, int swap, int I2,
                                 int KK, const int32_t* khw, float* grad, int accumulate, void* stream) {
   GAN_CHECK(part && khw && grad && nsplit > 0 && N_real <= N && C_real <= Cx, "wgrad_reduce: bad arguments");
-  const int64_t total = (int64_t)N_real * ntaps * C_real;
-  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  GAN_CHECK(Cx % 4 == 0 && ((uintptr_t)part % 16) == 0, "wgrad_reduce: Cx must be a multiple of 4 and part 16-byte aligned");
+  const int64_t total = (int64_t)N_real * ntaps * (Cx / 4);
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, part, nsplit, N, ntaps, Cx, N_real, C_real, swap,
                      I2, KK, khw, grad, accumulate);
   GAN_LAUNCH_CHECK();

@@ -74,6 +74,8 @@ class EmuOps:
         """Statement of gan_conv_patch_ok (csrc/conv_patch.hip)."""
         if c.x.dtype != 1 or c.Cin < 64 or c.Cin % 64 or c.Nw % 128 or c.Nst % 8 or c.out.C % 8 or c.max_tapoff <= 0:
             return False
+        if c.mask is not None and c.act != ACT_NONE:
+            return False
         m_img = c.Ho * c.Wo
         rows = min(256, m_img)
         wraps = (rows - 1) // c.Wo + 1
