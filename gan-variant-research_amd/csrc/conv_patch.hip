@@ -37,6 +37,12 @@ struct PatchArgs {
 };
 
 constexpr int BM = 256, BN = 128, NTHR = 512;
+// 8 waves = (8/WGN) pixel groups x WGN channel groups.  Measured on the 3x3 256->256 layer (s_memtime stamps, cycles per
+// 64-channel slab): 4 x 2 (64 x 64 per wave) 15.5 k, 2 x 4 (128 x 32 per wave, half the weight bytes through the vector L1,
+// twice the LDS reads) 16.0 k; MFMA alone would be 9.2 k.  Neither operand path is the limiter: with two waves per SIMD each
+// 16x16x32 MFMA holds the SIMD's issue port for 8 of its 16 cycles, so the 30-odd non-MFMA instructions of a k-step do not
+// hide.  The 4 x 2 split is kept (shorter first slab, fewer address registers).
+constexpr int WGN = 2, FI = BM / (8 / WGN) / 16, FJ = BN / WGN / 16;   // fragments per wave: FI pixel groups x FJ channel groups
 constexpr int RMAX = 448;                    // pixels per patch buffer (7 slices of 64)
 constexpr int NSLICE = RMAX / 64;
 constexpr int PATCHB = RMAX * 128;
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
     *reinterpret_cast<u32x4_t*>(pbuf + buf * PATCHB + j * 8192 + st_lds) = v;
   };
 
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int fr = lane & 15, fg = lane >> 4;
   // weights, fragment-major: byte offset of (n16, kb, lane) = ((n16*KB + kb)*64 + lane)*16
   // weights through a buffer descriptor: voffset = lane*16 (constant), everything else is a wave-uniform scalar offset,
@@ -90,20 +96,21 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
   const int lane16 = lane * 16;
   const int wn_u = __builtin_amdgcn_readfirstlane(wn);
-  auto w_load = [&](const TileGeo& g, int kb, u32x4_t (&f)[4]) {   // one MFMA k-step (32 channels) of this wave's 64 weight rows
-    const int n16 = (g.n0 + wn_u * 64) >> 4;
+  auto w_load = [&](int n0_tile, int kb, u32x4_t (&f)[FJ]) {   // one MFMA k-step (32 channels) of this wave's weight rows
+    const int base = __builtin_amdgcn_readfirstlane((((n0_tile + wn_u * (16 * FJ)) >> 4) * a.KB + kb) * 1024);   // provably wave-uniform: no waterfall
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      f[j] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, ((n16 + j) * a.KB + kb) * 1024, 0));
+    for (int j = 0; j < FJ; ++j)
+      f[j] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, base + j * a.KB * 1024, 0));
   };
-  auto kb_of = [&](int c, int t) { return (t * a.Cin + c * 64) >> 5; };
+  const bool dbg_w0 = a.stamps && ((uintptr_t)a.stamps & 2);   // diagnostic: every weight fetch reads block 0 (L1-resident)
+  auto kb_of = [&](int c, int t) { return dbg_w0 ? 0 : (t * a.Cin + c * 64) >> 5; };
 
   int nstamp = 0;
   auto stamp = [&]() {
     if (a.stamps && wave == 0 && nstamp < 32) {
       unsigned long long t;
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-      if (lane == 0) ((unsigned long long*)((uintptr_t)a.stamps & ~(uintptr_t)1))[blockIdx.x * 32 + nstamp] = t;
+      if (lane == 0) ((unsigned long long*)((uintptr_t)a.stamps & ~(uintptr_t)7))[blockIdx.x * 32 + nstamp] = t;
       ++nstamp;
     }
   };
@@ -117,17 +124,17 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
 #pragma unroll
     for (int j = 0; j < NSLICE; ++j) slab_store(0, j, tmp[j]);
   }
-  u32x4_t Wa[4], Wb[4], Xa[4], Xb[4];   // operand fragments of the even / odd k-step of a tap
-  w_load(g, kb_of(0, 0), Wa);
+  u32x4_t Wa[FJ], Wb[FJ], Xa[FI], Xb[FI];   // operand fragments of the even / odd k-step of a tap
+  w_load(g.n0, kb_of(0, 0), Wa);
   __syncthreads();   // tap table + slab 0 visible
   stamp();
 
   int pcur = 0;
   while (true) {
-    int lbase[4];
+    int lbase[FI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int m = g.m0 + wm * 64 + i * 16 + fr;
+    for (int i = 0; i < FI; ++i) {
+      int m = g.m0 + wm * (16 * FI) + i * 16 + fr;
       m = m < a.M_img ? m : a.M_img - 1;
       lbase[i] = pixbase(a, g.b, m) - g.P0;
     }
@@ -136,11 +143,11 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
     TileGeo gn = g;
     if (has_next) gn = tile_geo(a, tau_next);
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[FI][FJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     for (int c = 0; c < a.nchunk; ++c) {
       const bool last_chunk = c + 1 == a.nchunk;
@@ -153,44 +160,60 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
 
       // A fragments of one k-step of tap t: 4 x ds_read_b128 from the slab at the tap's row shift.  The second k-step's
       // chunk index differs by 4, i.e. its swizzled address is the first one's XOR 64.
-      uint32_t xaddr[4];
-      auto x_addr = [&](int t) {
-        const int toff = taptab[t];
+      uint32_t xaddr[FI];
+      auto x_addr = [&](int toff) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < FI; ++i) {
           const int prow = lbase[i] + toff;
           xaddr[i] = (uint32_t)(prow * 128 + ((fg ^ (prow & 7)) << 4));
         }
       };
-      auto x_load = [&](int kq, u32x4_t (&xf)[4]) {
+      auto x_load = [&](int kq, u32x4_t (&xf)[FI]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const u32x4_t*>(pb + (xaddr[i] ^ (kq ? 64u : 0u)));
+        for (int i = 0; i < FI; ++i) xf[i] = *reinterpret_cast<const u32x4_t*>(pb + (xaddr[i] ^ (kq ? 64u : 0u)));
       };
-      auto mma16 = [&](const u32x4_t (&wf)[4], const u32x4_t (&xf)[4]) {
+      // 16 MFMAs of one k-step in two parts, so that the next k-step's fetches can be issued AFTER the waits that guard this
+      // k-step's operands (a wait placed before the first MFMA would otherwise also cover the fetches just issued)
+      auto mma_part = [&](const u32x4_t (&wf)[FJ], const u32x4_t (&xf)[FI], int i0, int i1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FI; ++i)
+          if (i >= i0 && i < i1) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[j]), __builtin_bit_cast(bf16x8_t, xf[i]), acc[i][j], 0, 0, 0);
+            for (int j = 0; j < FJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[j]), __builtin_bit_cast(bf16x8_t, xf[i]), acc[i][j], 0, 0, 0);
+          }
       };
-      // Software pipeline at k-step granularity: while 16 MFMAs of one k-step run, the fragments of the next k-step are
-      // fetched (weights from L2/L1, activations from the LDS slab) into the other register set.
-      x_addr(0);
+      x_addr(taptab[0]);
       x_load(0, Xa);   // Wa was fetched by the previous slab's last step (or the prologue)
       for (int t = 0; t < a.ntaps; ++t) {
+        // where the NEXT tap's weights live: next tap, else first tap of the next slab, else of the next tile (branch-free scalars;
+        // after the very last tap this re-reads the current tile's first block, harmlessly)
         const bool last_tap = t + 1 == a.ntaps;
-        w_load(g, kb_of(c, t) + 1, Wb);
+        const int nt = last_tap ? 0 : t + 1;
+        const int nc = last_tap ? (last_chunk ? 0 : c + 1) : c;
+        const int nn0 = (last_tap && last_chunk) ? gn.n0 : g.n0;
+        const int kb_cur = kb_of(c, t), kb_next = kb_of(nc, nt);
+
+        __builtin_amdgcn_sched_barrier(0);
+        mma_part(Wa, Xa, 0, FI / 4);                 // waits for Wa / Xa (issued one k-step ago) land here
+        __builtin_amdgcn_sched_barrier(0);
+        w_load(g.n0, kb_cur + 1, Wb);
         x_load(1, Xb);
+        const int toff_next = taptab[last_tap ? t : t + 1];   // fetched a half step before x_addr needs it
         if (stage_next) {
           if (sj > 0 && sj <= NSLICE) slab_store(pcur ^ 1, sj - 1, stg);
           if (sj < NSLICE) stg = slab_load(gs, cs, sj);
           ++sj;
         }
-        mma16(Wa, Xa);
-        if (!last_tap) { w_load(g, kb_of(c, t + 1), Wa); x_addr(t + 1); x_load(0, Xa); }
-        else if (!last_chunk) w_load(g, kb_of(c + 1, 0), Wa);     // the next slab's activations wait for the barrier
-        else if (has_next) w_load(gn, kb_of(0, 0), Wa);
-        mma16(Wb, Xb);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_part(Wa, Xa, FI / 4, FI);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_part(Wb, Xb, 0, FI / 4);
+        __builtin_amdgcn_sched_barrier(0);
+        w_load(nn0, kb_next, Wa);
+        if (!last_tap) { x_addr(toff_next); x_load(0, Xa); }   // the next slab's activations wait for the barrier
+        __builtin_amdgcn_sched_barrier(0);
+        mma_part(Wb, Xb, FI / 4, FI);
       }
       // flush the slices the taps did not get to (few-tap layers), then hand the buffer over
       if (stage_next) {
@@ -212,23 +235,23 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
       constexpr bool MASK = decltype(mask_tag)::value;
       bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
       const bf16_t* mask = reinterpret_cast<const bf16_t*>(a.mask);
-      f32x4_t bq[4];   // bias of this lane's 4 channel quads
+      f32x4_t bq[FJ];   // bias of this lane's channel quads
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = g.n0 + wn * 64 + j * 16 + fg * 4;
+      for (int j = 0; j < FJ; ++j) {
+        const int n = g.n0 + wn * (16 * FJ) + j * 16 + fg * 4;
         bq[j] = (a.bias && n < a.Nst) ? *reinterpret_cast<const f32x4_t*>(a.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
       }
       const bool odd = fg & 1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = g.m0 + wm * 64 + i * 16 + fr;
+      for (int i = 0; i < FI; ++i) {
+        const int m = g.m0 + wm * (16 * FI) + i * 16 + fr;
         const bool mok = m < a.M_img;
         const int mm = mok ? m : a.M_img - 1;
         const int ho = mm / a.Wo, wo = mm - ho * a.Wo;
         const int64_t ob = ((int64_t)(g.b * a.out_Hp + ho * a.out_sy + a.out_y0) * a.out_Wp + wo * a.out_sx + a.out_x0) * a.out_C;
-        u32x2_t pk[4];
+        u32x2_t pk[FJ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < FJ; ++j) {
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -236,7 +259,7 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
             v[e] = ACT == GAN_ACT_RELU ? fmaxf(t, 0.f) : ACT == GAN_ACT_LRELU ? (t > 0.f ? t : 0.2f * t) : ACT == GAN_ACT_TANH ? tanhf(t) : t;
           }
           if (MASK) {
-            const int n = g.n0 + wn * 64 + j * 16 + fg * 4;
+            const int n = g.n0 + wn * (16 * FJ) + j * 16 + fg * 4;
             if (n < a.Nst) {
               const int64_t mb = ((int64_t)(g.b * a.mask_Hp + ho * a.out_sy + a.mask_y0) * a.mask_Wp + wo * a.out_sx + a.mask_x0) * a.out_C;
               const u32x2_t mv = *reinterpret_cast<const u32x2_t*>(mask + mb + n);
@@ -247,19 +270,16 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
           pk[j][0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
           pk[j][1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
         }
-        // lanes 16 apart hold the same pixel and adjacent channel quads: even fg keeps tiles 0 and 2, odd fg keeps 1 and 3;
-        // each sends the quads of the tiles it does not keep -> every lane ends with two 16-byte runs
-        uint32_t sx[4], rx[4];
-        sx[0] = odd ? pk[0][0] : pk[1][0]; sx[1] = odd ? pk[0][1] : pk[1][1];
-        sx[2] = odd ? pk[2][0] : pk[3][0]; sx[3] = odd ? pk[2][1] : pk[3][1];
+        // lanes 16 apart hold the same pixel and adjacent channel quads: of each pair of channel tiles even fg keeps the first
+        // and odd fg the second; each sends the quad of the tile it does not keep -> one 16-byte run per lane and tile pair
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rx[q] = (uint32_t)__shfl_xor((int)sx[q], 16, 64);
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
+        for (int jp = 0; jp < FJ / 2; ++jp) {
+          const uint32_t s0 = odd ? pk[2 * jp][0] : pk[2 * jp + 1][0], s1 = odd ? pk[2 * jp][1] : pk[2 * jp + 1][1];
+          const uint32_t r0 = (uint32_t)__shfl_xor((int)s0, 16, 64), r1 = (uint32_t)__shfl_xor((int)s1, 16, 64);
           u32x4_t st;
-          if (!odd) { st[0] = pk[2 * jp][0]; st[1] = pk[2 * jp][1]; st[2] = rx[2 * jp]; st[3] = rx[2 * jp + 1]; }
-          else      { st[0] = rx[2 * jp]; st[1] = rx[2 * jp + 1]; st[2] = pk[2 * jp + 1][0]; st[3] = pk[2 * jp + 1][1]; }
-          const int nst = g.n0 + wn * 64 + (2 * jp + (odd ? 1 : 0)) * 16 + (fg & 2) * 4;
+          if (!odd) { st[0] = pk[2 * jp][0]; st[1] = pk[2 * jp][1]; st[2] = r0; st[3] = r1; }
+          else      { st[0] = r0; st[1] = r1; st[2] = pk[2 * jp + 1][0]; st[3] = pk[2 * jp + 1][1]; }
+          const int nst = g.n0 + wn * (16 * FJ) + (2 * jp + (odd ? 1 : 0)) * 16 + (fg & 2) * 4;
           if (mok && nst < a.Nst) *reinterpret_cast<u32x4_t*>(out + ob + nst) = st;
         }
       }

@@ -2,7 +2,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 dev = torch.device("cuda:0")
 buf = torch.zeros(256 * 32, dtype=torch.int64, device=dev)
-os.environ["GAN_PATCH_STAMPS"] = str(buf.data_ptr() + (1 if len(sys.argv) > 1 else 0))
+os.environ["GAN_PATCH_STAMPS"] = str(buf.data_ptr() + (int(sys.argv[1]) if len(sys.argv) > 1 else 0))
 from gan_variant_research_amd import BF16
 from gan_variant_research_amd.convplan import ConvLayer
 from gan_variant_research_amd.runtime import Ctx, HipOps
