@@ -6,8 +6,8 @@
 One "step" = one call of CutTrainer.train_step (GAN_Variant1/training/train_cutpp.py:206-331 of the reference): shared
 G forward, D step (+ lazy R1 every 16th step), G step with PatchNCE and identity loss, fused clip+Adam+EMA updates,
 on synthetic inputs already resident in HBM.  Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     -- the dominant kernel (3x3 256->256 implicit-GEMM conv forward, 77.3 GFLOP per launch at B=16) timed
-                  live with HIP events on the launch stream, against the dense bf16 MFMA peak;
+  roofline     -- the dominant kernel (conv_patch_kernel: all of its launches of one step) timed live with HIP events on the
+                  launch stream, against the dense bf16 MFMA peak;
   cpu_baseline -- the PyTorch-CPU oracle's train step timed on this host's cores on a bounded sample (B=2).
 """
 from __future__ import annotations
@@ -42,31 +42,46 @@ def default_config():
     }
 
 
-def dominant_kernel_roofline(trainer, iters=20):
-    """Times the 3x3 256->256 reflect-padded conv forward (conv_igemm_kernel<bf16,2,2,4>) of one residual block with HIP
-    events on the stream it is launched on.  Algorithmic FLOPs per launch = 2*M*N*K, M = B*(S/4)^2, N = 256, K = 2304."""
-    p1, net = trainer.p1, trainer.G
-    conv = net.c_blk[0][0]
-    x, y = p1.acts[2], p1.raw[3][0]
-    ops = conv.fwd(x, y)
-    for _ in range(3):
+def dominant_kernel_roofline(trainer, iters=10):
+    """Roofline of the dominant kernel of the step, measured live.
+
+    bf16: `conv_patch_kernel` (csrc/conv_patch.hip) -- every convolution / input-gradient launch of one non-R1 step that the
+    range-patch path takes (the 3x3 256->256 residual convolutions and their dgrads, ConvT phases, deep D layers).  All of
+    them are replayed back to back `iters` times between two HIP events on the launch stream, so that
+      ms_per_launch = elapsed / (iters * launches)  is the figure `rocprofv3 --kernel-trace --stats` reports as the kernel's
+      average duration for the same step (profiles/), and
+      achieved = sum of algorithmic FLOPs (2 * B*Ho*Wo * Nst * Cin * ntaps per launch) / elapsed.
+    fp32 (--fp32): the same over every `conv_igemm_kernel` launch.  The single 3x3 256->256 forward (77.3 GFLOP at B=16) is
+    reported beside it as `res_fwd_*`."""
+    bf16 = trainer.amp.enabled
+    progs = [trainer.prog_gfwd, trainer.prog_d_compute, trainer.prog_d_update, trainer.prog_g_compute, trainer.prog_g_identity, trainer.prog_g_update]
+    calls = [o for p in progs for o in p.ops if getattr(o, "conv", None) is not None and (o.conv.w_frag or not bf16)]
+    flops = sum(2.0 * o.conv.B * o.conv.Ho * o.conv.Wo * o.conv.Nst * o.conv.Cin * o.conv.ntaps for o in calls)
+
+    def timed(ops, n):
         for o in ops:
             o()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        for o in ops:
-            o()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    m, n, k = x.B * y.H * y.W, conv.cout, conv.cin * 9
-    flops = 2.0 * m * n * k
-    peak = PEAK_BF16_TFLOPS if trainer.amp.enabled else PEAK_F32_TFLOPS
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            for o in ops:
+                o()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    ms = timed(calls, iters)
+    conv = trainer.G.c_blk[0][0]
+    x, y = trainer.p1.acts[2], trainer.p1.raw[3][0]
+    res_ms = timed(conv.fwd(x, y), 20)
+    res_flops = 2.0 * x.B * y.H * y.W * conv.cout * conv.cin * 9
+    peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
     ach = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-            "kernel": "conv_igemm_kernel<%s,2,2,4> 3x3 256->256 fwd" % ("bf16" if trainer.amp.enabled else "f32"),
-            "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
+            "kernel": "conv_patch_kernel" if bf16 else "conv_igemm_kernel<float,...>",
+            "launches_per_step": len(calls), "flop_per_step": flops, "ms_per_launch": round(ms / max(len(calls), 1), 5),
+            "share_of_step_conv_flop": round(flops / (GFLOP_PER_IMAGE * 1e9 * x.B), 3),
+            "res_fwd_tflops": round(res_flops / (res_ms * 1e-3) / 1e12, 2), "res_fwd_ms": round(res_ms, 4)}
 
 
 def cpu_baseline(image_size=256, batch=2, steps=2):

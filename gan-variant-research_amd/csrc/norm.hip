@@ -7,6 +7,7 @@
 // All kernels are HBM-bound: every access is one 16-byte channel chunk per lane, consecutive lanes on
 // consecutive chunks of a pixel (halo-NHWC rows are contiguous), statistics accumulate in fp32 and are
 // combined in fp64.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -391,15 +392,22 @@ int check_lanes(const gan_view* v, const char* what) {
   return 0;
 }
 // row-chunks per image for the statistics passes: ~2048 16-byte loads per block, at most MAXCH (workspace bound)
+int work_per_block() {   // 16-byte loads per block; GAN_NORM_WORK overrides (tuning aid)
+  static int w = 0;
+  if (!w) { const char* e = getenv("GAN_NORM_WORK"); w = e ? atoi(e) : 2048; if (w < 256) w = 256; }
+  return w;
+}
 int nchunks_for(int HW, int cl) {
-  int64_t n = ((int64_t)HW * cl + 2047) / 2048;
+  const int W = work_per_block();
+  int64_t n = ((int64_t)HW * cl + W - 1) / W;
   if (n < 1) n = 1;
   if (n > MAXCH) n = MAXCH;
   return (int)n;
 }
 // blocks per image for the apply passes (no workspace bound)
 int nblocks_for(int pixels, int cl) {
-  int64_t n = ((int64_t)pixels * cl + 2047) / 2048;
+  const int W = work_per_block();
+  int64_t n = ((int64_t)pixels * cl + W - 1) / W;
   if (n < 1) n = 1;
   if (n > 1024) n = 1024;
   return (int)n;

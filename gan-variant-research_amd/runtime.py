@@ -216,7 +216,9 @@ class HipOps:
 
     def conv_igemm(self, c: ConvCall) -> Op:
         self._keep.append(c)
-        return self._call("gan_conv_igemm", C.byref(self._conv_desc(c)), self._s())
+        op = self._call("gan_conv_igemm", C.byref(self._conv_desc(c)), self._s())
+        op.conv = c   # lets bench.py enumerate a program's convolution launches and price them
+        return op
 
     def _wgrad_desc(self, c: WgradCall) -> GanWgradDesc:
         d = GanWgradDesc()
@@ -236,7 +238,9 @@ class HipOps:
     def conv_wgrad(self, c: WgradCall) -> Op:
         self._keep.append(c)
         assert c.part.numel() >= c.nsplit * c.N * c.ntaps * c.Cx
-        return self._call("gan_conv_wgrad", C.byref(self._wgrad_desc(c)), self._s())
+        op = self._call("gan_conv_wgrad", C.byref(self._wgrad_desc(c)), self._s())
+        op.wgrad = c
+        return op
 
     def wgrad_reduce(self, part, nsplit, N, ntaps, Cx, N_real, C_real, swap, I2, KK, khw, grad, accumulate) -> Op:
         return self._call("gan_wgrad_reduce", self._p(part), nsplit, N, ntaps, Cx, N_real, C_real, int(swap), I2, KK, self._p(khw),
