@@ -43,6 +43,11 @@ class GanAdamTensor(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("ema", vp), ("numel", i64), ("step", vp), ("_pad", i64)]
 
 
+class GanPackDesc(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("khw", vp), ("dtype", i32), ("Nw", i32), ("ntaps", i32), ("Cin", i32), ("N_real", i32), ("C_real", i32),
+                ("swap", i32), ("I2", i32), ("KK", i32), ("layout", i32), ("first_block", i32), ("nblocks", i32)]
+
+
 PV, PC, PW = C.POINTER(GanView), C.POINTER(GanConvDesc), C.POINTER(GanWgradDesc)
 
 # name -> (restype, argtypes); must list every function of include/mi355x_gan.h
@@ -55,6 +60,7 @@ PROTOTYPES = {
     "gan_wgrad_reduce": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "gan_conv_patch_ok": (C.c_int, [PC]),
     "gan_pack_weight": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "gan_pack_weight_batch": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "gan_bias_grad": (C.c_int, [PV, C.c_int, vp, C.c_int, vp, vp]),
     "gan_in_stats": (C.c_int, [PV, f32, vp, vp, vp]),
     "gan_in_finalize": (C.c_int, [vp, C.c_int, C.c_int, f32, vp]),

@@ -36,13 +36,14 @@ struct PatchArgs {
   unsigned long long* stamps;   // diagnostic build only (GAN_PATCH_STAMPS): [block][32] s_memtime stamps of wave 0
 };
 
-constexpr int BM = 256, BN = 128, NTHR = 512;
+constexpr int BN = 128, NTHR = 512;   // the tile height BM is a template parameter: 256 (4 x 2 waves of 64 x 64) or 288 (2 x 4 waves of 144 x 32)
 // 8 waves = (8/WGN) pixel groups x WGN channel groups.  Measured on the 3x3 256->256 layer (s_memtime stamps, cycles per
 // 64-channel slab): 4 x 2 (64 x 64 per wave) 15.5 k, 2 x 4 (128 x 32 per wave, half the weight bytes through the vector L1,
 // twice the LDS reads) 16.0 k; MFMA alone would be 9.2 k.  Neither operand path is the limiter: with two waves per SIMD each
 // 16x16x32 MFMA holds the SIMD's issue port for 8 of its 16 cycles, so the 30-odd non-MFMA instructions of a k-step do not
 // hide.  The 4 x 2 split is kept (shorter first slab, fewer address registers).
-constexpr int WGN = 2, FI = BM / (8 / WGN) / 16, FJ = BN / WGN / 16;   // fragments per wave: FI pixel groups x FJ channel groups
+// Tile 288 x 128 exists for tile-count quantisation: the 66x66 input-gradient domain is 4356 pixels per image = 18 tiles of 256
+// (576 tiles = 2.25 waves on 256 CUs -> 3 rounds) but 16 tiles of 288 (512 tiles -> 2 rounds of 1.125x the work: -25 %).
 constexpr int RMAX = 448;                    // pixels per patch buffer (7 slices of 64)
 constexpr int NSLICE = RMAX / 64;
 constexpr int PATCHB = RMAX * 128;
@@ -54,6 +55,7 @@ __device__ __forceinline__ int pixbase(const PatchArgs& a, int b, int m) {
   const int ho = m / a.Wo, wo = m - ho * a.Wo;
   return (b * a.in_Hp + ho * a.in_sy + a.in_y0) * a.in_Wp + wo * a.in_sx + a.in_x0;
 }
+template <int BM>
 __device__ __forceinline__ TileGeo tile_geo(const PatchArgs& a, int tau) {
   TileGeo g;
   const int mt = tau / a.NTILES;
@@ -64,7 +66,9 @@ __device__ __forceinline__ TileGeo tile_geo(const PatchArgs& a, int tau) {
   return g;
 }
 
+template <int BM, int WGN>
 __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
+  constexpr int FI = BM / (8 / WGN) / 16, FJ = BN / WGN / 16;   // fragments per wave: FI pixel groups x FJ channel groups
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   char* pbuf = lds;                       // [2][PATCHB]
   int32_t* taptab = reinterpret_cast<int32_t*>(lds + 2 * PATCHB);
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
     }
   };
   stamp();
-  TileGeo g = tile_geo(a, tau);
+  TileGeo g = tile_geo<BM>(a, tau);
   // prologue: first slab -> LDS buffer 0, first tap's weights -> registers
   {
     u32x4_t tmp[NSLICE];
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
     const int tau_next = tau + G;
     const bool has_next = tau_next < a.tiles;
     TileGeo gn = g;
-    if (has_next) gn = tile_geo(a, tau_next);
+    if (has_next) gn = tile_geo<BM>(a, tau_next);
 
     f32x4_t acc[FI][FJ];
 #pragma unroll
@@ -300,6 +304,16 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
 
 }  // namespace
 
+// pixels of the contiguous input range a tile of BM output pixels reads (all taps)
+static int patch_span(const gan_conv_desc* d, int BM) {
+  const int M_img = d->Ho * d->Wo;
+  const int maxtap = d->max_tapoff / d->Cin;
+  const int rows = BM < M_img ? BM : M_img;
+  const int wraps = (rows - 1) / d->Wo + 1;
+  const int jump = d->in_Wp * d->in_sy - d->Wo * d->in_sx;
+  return (rows - 1) * d->in_sx + wraps * (jump > 0 ? jump : 0) + maxtap + 1;
+}
+
 // Pure predicate (no device access): does this descriptor qualify for the range-patch kernel?  The planner asks at
 // build time because qualifying calls need the fragment-major weight packing (gan_pack_weight layout 1).
 extern "C" int gan_conv_patch_ok(const gan_conv_desc* d) {
@@ -309,19 +323,25 @@ extern "C" int gan_conv_patch_ok(const gan_conv_desc* d) {
   if (d->mask && d->act != GAN_ACT_NONE) return 0;   // the masked epilogue is specialised for act = none
   if (d->dtype != GAN_BF16 || d->Cin < 64 || d->Cin % 64 != 0 || d->Nw % BN != 0 || d->Nst % 8 != 0 || d->out_C % 8 != 0) return 0;
   if (d->max_tapoff <= 0 || d->ntaps < 1) return 0;
-  const int M_img = d->Ho * d->Wo;
-  const int maxtap = d->max_tapoff / d->Cin;
-  const int rows = BM < M_img ? BM : M_img;
-  const int wraps = (rows - 1) / d->Wo + 1;
-  const int jump = d->in_Wp * d->in_sy - d->Wo * d->in_sx;
-  const int span = (rows - 1) * d->in_sx + wraps * (jump > 0 ? jump : 0) + maxtap + 1;
-  return span <= RMAX ? 1 : 0;
+  return patch_span(d, 256) <= RMAX || patch_span(d, 288) <= RMAX ? 1 : 0;
 }
 
 int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   if (!gan_conv_patch_ok(d)) return gan_set_error(-1, "conv: w_layout=1 (fragment-major weights) but the descriptor does not qualify for the range-patch kernel");
   PatchArgs a;
   const int M_img = d->Ho * d->Wo;
+  const int ncu = 256;
+  // tile height: the one that needs the fewest CU-rounds x rows (GAN_PATCH_BM forces one; tuning aid)
+  int BM = 0;
+  int64_t best = 0;
+  int forced = 0;
+  { const char* e = getenv("GAN_PATCH_BM"); forced = e ? atoi(e) : 0; }   // read per launch so a test can toggle it
+  for (int cand : {256, 288}) {
+    if (patch_span(d, cand) > RMAX || (forced && forced != cand && patch_span(d, forced) <= RMAX)) continue;
+    const int64_t tiles = (int64_t)d->B * ((M_img + cand - 1) / cand) * ((d->Nst + BN - 1) / BN);
+    const int64_t cost = ((tiles + ncu - 1) / ncu) * cand;
+    if (!BM || cost < best) { BM = cand; best = cost; }
+  }
   a.in = (const char*)d->in; a.w = (const char*)d->w; a.bias = d->bias; a.out = (char*)d->out; a.mask = (const char*)d->mask; a.tapoff = d->tapoff;
   a.B = d->B; a.M_img = M_img; a.Wo = d->Wo; a.MT_img = (M_img + BM - 1) / BM; a.NTILES = (d->Nst + BN - 1) / BN;
   a.tiles = a.B * a.MT_img * a.NTILES;
@@ -333,15 +353,16 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   a.Nst = d->Nst; a.act = d->act;
   a.mask_Hp = d->mask_Hp; a.mask_Wp = d->mask_Wp; a.mask_y0 = d->mask_y0; a.mask_x0 = d->mask_x0;
   { const char* e = getenv("GAN_PATCH_STAMPS"); a.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
+  const int grid = a.tiles < ncu ? a.tiles : ncu;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv_patch_kernel<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv_patch_kernel<288, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return gan_set_error(-2, "conv_patch: cannot raise the dynamic LDS limit to %d bytes", LDS_BYTES);
     attr_set = true;
   }
-  const int ncu = 256;
-  const int grid = a.tiles < ncu ? a.tiles : ncu;
-  hipLaunchKernelGGL(conv_patch_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
+  if (BM == 256) hipLaunchKernelGGL((conv_patch_kernel<256, 2>), dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
+  else hipLaunchKernelGGL((conv_patch_kernel<288, 4>), dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
   if (hipGetLastError() != hipSuccess) return gan_set_error(-2, "conv_patch: launch failed");
   return 0;
 }

@@ -45,9 +45,11 @@ class _Net:
         return layer
 
     def repack_program(self) -> Program:
+        """Refreshes every operand copy of the network after an optimiser step: ONE batched launch."""
         prog = Program("repack")
-        for layer in self.layers:
-            prog.add(layer.repack_ops())
+        ops = [op for layer in self.layers for op in layer.repack_ops()]
+        if ops:
+            prog.add(self.ctx.ops.pack_weight_batch([op.pack_args for op in ops]))
         return prog
 
     def gbuf(self, tag: str, B, H, W, C, halo) -> View:

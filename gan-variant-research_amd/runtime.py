@@ -247,8 +247,24 @@ class HipOps:
                           self._p(grad), int(accumulate), self._s())
 
     def pack_weight(self, src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, swap, I2, KK, khw, layout=0) -> Op:
-        return self._call("gan_pack_weight", self._p(src), self._p(dst), dtype, Nw, ntaps, Cin, N_real, C_real, int(swap), I2, KK,
-                          self._p(khw), int(layout), self._s())
+        op = self._call("gan_pack_weight", self._p(src), self._p(dst), dtype, Nw, ntaps, Cin, N_real, C_real, int(swap), I2, KK,
+                        self._p(khw), int(layout), self._s())
+        op.pack_args = (src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, int(swap), I2, KK, khw, int(layout))
+        return op
+
+    def pack_weight_batch(self, packs) -> Op:
+        """One launch for many operand copies; `packs` = the pack_args tuples of ops built by pack_weight."""
+        arr = (_lib.GanPackDesc * len(packs))()
+        first = 0
+        for d, (src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, swap, I2, KK, khw, layout) in zip(arr, packs):
+            assert layout == 0 or (Nw % 16 == 0 and (ntaps * Cin) % 32 == 0)
+            self._keep.extend((src, dst, khw))
+            d.src, d.dst, d.khw = src.data_ptr(), dst.data_ptr(), khw.data_ptr()
+            d.dtype, d.Nw, d.ntaps, d.Cin, d.N_real, d.C_real, d.swap, d.I2, d.KK, d.layout = dtype, Nw, ntaps, Cin, N_real, C_real, swap, I2, KK, layout
+            d.nblocks = max(1, min(512, (Nw * ntaps * Cin + 1023) // 1024))
+            d.first_block, first = first, first + d.nblocks
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        return self._call("gan_pack_weight_batch", self._p(table), len(packs), first, self._s())
 
     def bias_grad(self, g: View, N_real, grad, accumulate, ws) -> Op:
         return self._call("gan_bias_grad", self._v(g), N_real, self._p(grad), int(accumulate), self._p(ws), self._s())

@@ -105,6 +105,14 @@ int gan_wgrad_reduce(const float* part, int nsplit, int N, int ntaps, int Cx, in
  * (((n/16)*(ntaps*Cin/32) + k/32)*64 + ((k%32)/8)*16 + n%16)*8 + k%8 (one MFMA operand fragment = 1 KB contiguous) */
 int gan_pack_weight(const float* src, void* dst, int dtype, int Nw, int ntaps, int Cin, int N_real, int C_real, int swap,
                     int I2, int KK, const int32_t* khw, int layout, void* stream);
+/* gan_pack_weight for many operand copies in one launch.  `descs` is a DEVICE array of n descriptors (fields as the arguments
+ * of gan_pack_weight); the caller assigns each a contiguous block range: first_block = running sum of nblocks (256 threads per
+ * block, any nblocks >= 1), total_blocks = their sum.  Validation of each descriptor is the caller's (same rules). */
+typedef struct gan_pack_desc {
+  const float* src; void* dst; const int32_t* khw;
+  int32_t dtype, Nw, ntaps, Cin, N_real, C_real, swap, I2, KK, layout, first_block, nblocks;
+} gan_pack_desc;
+int gan_pack_weight_batch(const gan_pack_desc* descs, int n, int total_blocks, void* stream);
 /* bias gradient: grad[n] (+)= sum over logical pixels of g[...,n], n < N_real (column sums of dY) */
 int gan_bias_grad(const gan_view* g, int N_real, float* grad, int accumulate, float* ws, void* stream);
 

@@ -192,6 +192,15 @@ class EmuOps:
                 K = ntaps * Cin
                 out = out.view(Nw // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4)
             dst.view(-1).copy_(out.reshape(-1).to(dst.dtype))
+        op.pack_args = (src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, int(swap), I2, KK, khw, int(layout))
+        return op
+
+    def pack_weight_batch(self, packs):
+        ops = [self.pack_weight(*a) for a in packs]
+
+        def op():
+            for o in ops:
+                o()
         return op
 
     def bias_grad(self, g, N_real, grad, accumulate, ws):

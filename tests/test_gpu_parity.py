@@ -22,6 +22,13 @@ def test_conv_geometry_hip(geom, dtype):
     cases.run_conv_geometry(hip_ctx(dtype), geom, dtype, B=3)
 
 
+@pytest.mark.parametrize("geom", [g for g in cases.GEOMS if max(g[0], g[1]) >= 64])
+def test_conv_geometry_hip_tile288(geom, monkeypatch):
+    """The 288-row tile of the range-patch kernel is only chosen on large launches (tile-count quantisation); force it."""
+    monkeypatch.setenv("GAN_PATCH_BM", "288")
+    cases.run_conv_geometry(hip_ctx(BF16), geom, BF16, B=3)
+
+
 # ---------------------------------------------------------------------------------------------- op twins
 class Twin:
     """The same buffers on CPU (emulator) and GPU (HIP); ops are built on both and every buffer is compared afterwards."""
@@ -94,6 +101,18 @@ def test_instance_norm_twins(shape, dtype):
         dc, dg = tw.view(B, H, W, C, 2, rand=False)
         fold = halo if H >= 2 * halo + 2 else 0
         tw.run(tw.c.ops.in_bwd(xc, sc, act, gc, bool(fold), g2c, dc, wc), tw.g.ops.in_bwd(xg, sg, act, gg, bool(fold), g2g, dg, wg))
+        tw.check(TOL[dtype][0] * 5, TOL[dtype][1] * 5)
+        # the same backward with the fused bias gradient, twice (the second call accumulates)
+        nb = max(1, C - 3)
+        bc, bg = tw.f32(torch.zeros(nb))
+        w2c, w2g = tw.f32(torch.zeros(B * 96 * C * 2 + B * C * 2 + (B * 1024 + 32) * C))
+        tw.tensors.pop()
+        for acc in (False, True):
+            tw.run(tw.c.ops.in_bwd_bias(xc, sc, act, gc, bool(fold), g2c, dc, w2c, bc, nb, acc),
+                   tw.g.ops.in_bwd_bias(xg, sg, act, gg, bool(fold), g2g, dg, w2g, bg, nb, acc))
+        # column sums of dx are zero in exact arithmetic (non-affine norm): what is compared is rounding noise of B*H*W addends
+        np.testing.assert_allclose(bg.cpu().numpy(), bc.numpy(), rtol=TOL[dtype][0] * 5, atol=TOL[dtype][1] * 5 * (B * H * W) ** 0.5)
+        tw.tensors.pop()   # bias compared above with a magnitude-aware tolerance
         tw.check(TOL[dtype][0] * 5, TOL[dtype][1] * 5)
         oc, og = tw.view(B, H, W, C, 0, rand=False)
         tw.run(tw.c.ops.fold_add(g2c, gc, bool(fold), oc), tw.g.ops.fold_add(g2g, gg, bool(fold), og))
