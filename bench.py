@@ -77,11 +77,25 @@ def dominant_kernel_roofline(trainer, iters=10):
     res_flops = 2.0 * x.B * y.H * y.W * conv.cout * conv.cin * 9
     peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": pmc_traffic("conv_patch_kernel") if bf16 else None,
             "kernel": "conv_patch_kernel" if bf16 else "conv_igemm_kernel<float,...>",
             "launches_per_step": len(calls), "flop_per_step": flops, "ms_per_launch": round(ms / max(len(calls), 1), 5),
             "share_of_step_conv_flop": round(flops / (GFLOP_PER_IMAGE * 1e9 * x.B), 3),
             "res_fwd_tflops": round(res_flops / (res_ms * 1e-3) / 1e12, 2), "res_fwd_ms": round(res_ms, 4)}
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+    command (profiles/rNN_pmc_traffic.json, written by tools/pmc_traffic.py with the guide's gfx950 correction: FETCH_SIZE x 2);
+    averaged over the kernel's instantiations, weighted by launches.  None if no pass has been committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    rows = [v for k, v in json.load(open(files[-1])).items() if k.startswith(kernel_prefix)]
+    n = sum(r["launches"] for r in rows)
+    return round(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n) if n else None
 
 
 def cpu_baseline(image_size=256, batch=2, steps=2):

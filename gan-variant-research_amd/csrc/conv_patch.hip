@@ -76,7 +76,10 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < a.ntaps; i += NTHR) taptab[i] = a.tapoff[i] / a.Cin;   // pixel offsets
   const int G = gridDim.x;
-  int tau = blockIdx.x;
+  // XCD-aware start tile: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), and the NTILES channel tiles
+  // of one pixel tile (consecutive tau) read the same input patch -> give consecutive tau to workgroups of ONE XCD so the
+  // patch is fetched into one L2 once (PMC: 97 MB fetched per launch against 37 MB of input)
+  int tau = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   if (tau >= a.tiles) return;
 
   // slab staging role: patch row r = 64*j + wave*8 + (lane>>3); LDS position p = lane&7 holds source chunk p ^ (r&7)
