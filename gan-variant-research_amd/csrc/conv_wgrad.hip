@@ -41,7 +41,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
   __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int jt = blockIdx.x % a.JTILES, nt = (blockIdx.x / a.JTILES) % a.NTILES, sp = blockIdx.x / (a.JTILES * a.NTILES);
+  // XCD-aware ids: workgroups are dealt round-robin over the 8 XCDs; the JTILES*NTILES blocks of one pixel split read the
+  // same x / dY ranges, so consecutive logical ids go to ONE XCD (x of the 7x7 layers was fetched from HBM 11x over).
+  const int grid_q = gridDim.x >> 3, grid_r = gridDim.x & 7, xcd = blockIdx.x & 7;
+  const int bid = xcd * grid_q + min(xcd, grid_r) + (int)(blockIdx.x >> 3);
+  const int jt = bid % a.JTILES, nt = (bid / a.JTILES) % a.NTILES, sp = bid / (a.JTILES * a.NTILES);
   const int j0 = jt * JT, n0 = nt * NTILE;
   const int m_begin = sp * a.Ms, m_end = min(a.M, m_begin + a.Ms);
   const int nk = (m_end - m_begin + KM - 1) / KM;

@@ -45,7 +45,9 @@ __global__ __launch_bounds__(512) void wgrad_patch_kernel(WpArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  int bid = blockIdx.x;
+  // XCD-aware: the NBLK*CBLK blocks of one pixel split share its dY tile / x window; workgroups b and b+8 share an XCD, so
+  // hand consecutive ids to one XCD (the split's operands are then fetched into one L2 once)
+  int bid = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int cb = bid % a.CBLK; bid /= a.CBLK;
   const int nb = bid % a.NBLK; bid /= a.NBLK;
   const int sp = bid;                                  // split index: image b = sp / spi, sub-range sp % spi
