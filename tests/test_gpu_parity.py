@@ -163,7 +163,8 @@ def test_layout_and_losses_twins(dtype):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
-@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 1, 256), (3, 8, 8, 256, 1, 64), (2, 12, 12, 128, 0, 144)])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 1, 256), (3, 8, 8, 256, 1, 64), (2, 12, 12, 128, 0, 144),   # MFMA tiling
+                                   (2, 12, 12, 32, 0, 100), (2, 8, 8, 512, 1, 48)])                            # scalar-FMA fallback
 def test_patchnce_twins(shape, dtype):
     B, H, W, C, halo, P = shape
     tw = Twin(dtype, seed=5)
