@@ -23,30 +23,52 @@ template <typename T> struct Lanes {
 };
 
 __device__ __forceinline__ void pixel_yx(int p, int W, int& y, int& x) { y = p / W; x = p - y * W; }
+// (y, x) of pixel p + step without a division per pixel; returns the number of row wraps
+__device__ __forceinline__ int pixel_step(int step, int W, int& y, int& x) {
+  x += step;
+  int wraps = 0;
+  while (x >= W) { x -= W; ++y; ++wraps; }
+  return wraps;
+}
+// element offset of a view's current pixel, advanced with the walk (these kernels were VALU-bound on 64-bit address
+// arithmetic: ~100 instructions per 3 memory operations)
+struct Off {
+  int64_t o, dstep, dwrap;
+  __device__ __forceinline__ Off(const DView& v, int b, int y, int x, int step, int W) : o(v.pix(b, y, x)), dstep((int64_t)step * v.C), dwrap((int64_t)(v.Wp - W) * v.C) {}
+  __device__ __forceinline__ void advance(int wraps) { o += dstep + wraps * dwrap; }
+};
 
 // sum of the padded-domain gradient over the reflect pre-images of logical pixel (y,x); pad = g.y0
 template <typename T>
-__device__ __forceinline__ void load_folded(const DView& g, int fold, int b, int y, int x, int cofs, float* v) {
+__device__ __forceinline__ void load_folded(const DView& g, int fold, int b, int y, int x, int64_t off, int cofs, float* v) {
   constexpr int N = Chunk<T>::N;
   const T* p = reinterpret_cast<const T*>(g.ptr);
-  Chunk<T>::load(p + g.pix(b, y, x) + cofs, v);
+  Chunk<T>::load(p + off + cofs, v);   // off = g.pix(b, y, x), maintained incrementally by the caller
   if (!fold) return;
+  // mirror partners in the padded domain (-1: none).  Nearly every pixel has none: one compare pair, no extra loads.
   const int py = g.y0, px = g.x0;
-  int ys[2], xs[2], ny = 1, nx = 1;
-  ys[0] = y + py; xs[0] = x + px;
-  if (y >= 1 && y <= py) ys[ny++] = py - y;
-  else if (y >= g.H - 1 - py && y <= g.H - 2) ys[ny++] = 2 * (g.H - 1) - y + py;
-  if (x >= 1 && x <= px) xs[nx++] = px - x;
-  else if (x >= g.W - 1 - px && x <= g.W - 2) xs[nx++] = 2 * (g.W - 1) - x + px;
-  if (ny == 1 && nx == 1) return;
-  for (int i = 0; i < ny; ++i)
-    for (int j = 0; j < nx; ++j) {
-      if (i == 0 && j == 0) continue;
-      float t[N];
-      Chunk<T>::load(p + g.pixp(b, ys[i], xs[j]) + cofs, t);
+  int y2 = -1, x2 = -1;
+  if (y >= 1 && y <= py) y2 = py - y;
+  else if (y >= g.H - 1 - py && y <= g.H - 2) y2 = 2 * (g.H - 1) - y + py;
+  if (x >= 1 && x <= px) x2 = px - x;
+  else if (x >= g.W - 1 - px && x <= g.W - 2) x2 = 2 * (g.W - 1) - x + px;
+  if ((y2 & x2) < 0 && (y2 | x2) < 0) return;   // both -1
+  float t[N];
+  if (x2 >= 0) {
+    Chunk<T>::load(p + g.pixp(b, y + py, x2) + cofs, t);
+#pragma unroll
+    for (int e = 0; e < N; ++e) v[e] += t[e];
+  }
+  if (y2 >= 0) {
+    Chunk<T>::load(p + g.pixp(b, y2, x + px) + cofs, t);
+#pragma unroll
+    for (int e = 0; e < N; ++e) v[e] += t[e];
+    if (x2 >= 0) {
+      Chunk<T>::load(p + g.pixp(b, y2, x2) + cofs, t);
 #pragma unroll
       for (int e = 0; e < N; ++e) v[e] += t[e];
     }
+  }
 }
 
 // ------------------------------------------------------------------ forward statistics
@@ -61,10 +83,11 @@ __global__ __launch_bounds__(NTHR) void in_partial_kernel(DView x, int nch, floa
   float s[N], q[N];
 #pragma unroll
   for (int e = 0; e < N; ++e) s[e] = q[e] = 0.f;
-  for (int p = p0 + L.rl; p < p1; p += L.RL) {
-    int y, xx; pixel_yx(p, x.W, y, xx);
+  int y, xx; pixel_yx(p0 + L.rl, x.W, y, xx);
+  Off ox(x, b, y, xx, L.RL, x.W);
+  for (int p = p0 + L.rl; p < p1; p += L.RL, ox.advance(pixel_step(L.RL, x.W, y, xx))) {
     float v[N];
-    Chunk<T>::load(xp + x.pix(b, y, xx) + L.cl * N, v);
+    Chunk<T>::load(xp + ox.o + L.cl * N, v);
 #pragma unroll
     for (int e = 0; e < N; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
   }
@@ -137,8 +160,8 @@ __global__ __launch_bounds__(NTHR) void in_apply_kernel(DView x, const float* __
   const T* xp = reinterpret_cast<const T*>(x.ptr);
   const T* rp = reinterpret_cast<const T*>(res.ptr);
   T* yp = reinterpret_cast<T*>(y.ptr);
-  for (int p = p0 + L.rl; p < p1; p += L.RL) {
-    int dy, dx; pixel_yx(p, DW, dy, dx);
+  int dy, dx; pixel_yx(p0 + L.rl, DW, dy, dx);
+  for (int p = p0 + L.rl; p < p1; p += L.RL, pixel_step(L.RL, DW, dy, dx)) {
     int sy = dy, sx = dx;
     if (padded) { sy = reflect_idx(dy - y.y0, y.H); sx = reflect_idx(dx - y.x0, y.W); }
     float v[N];
@@ -159,13 +182,14 @@ __global__ __launch_bounds__(NTHR) void in_apply_kernel(DView x, const float* __
 // ------------------------------------------------------------------ backward
 template <typename T>
 __device__ __forceinline__ void in_bwd_g(const DView& x, const float* mean, const float* rstd, int act, const DView& gy, int fold,
-                                         const DView& g2, int has_g2, int b, int yy, int xx, int cofs, float* g, float* xh) {
+                                         const DView& g2, int has_g2, int b, int yy, int xx, int cofs, int64_t offx, int64_t offg,
+                                         int64_t offg2, float* g, float* xh) {
   constexpr int N = Chunk<T>::N;
-  Chunk<T>::load(reinterpret_cast<const T*>(x.ptr) + x.pix(b, yy, xx) + cofs, xh);
-  load_folded<T>(gy, fold, b, yy, xx, cofs, g);
+  Chunk<T>::load(reinterpret_cast<const T*>(x.ptr) + offx + cofs, xh);
+  load_folded<T>(gy, fold, b, yy, xx, offg, cofs, g);
   if (has_g2) {
     float t[N];
-    Chunk<T>::load(reinterpret_cast<const T*>(g2.ptr) + g2.pix(b, yy, xx) + cofs, t);
+    Chunk<T>::load(reinterpret_cast<const T*>(g2.ptr) + offg2 + cofs, t);
 #pragma unroll
     for (int e = 0; e < N; ++e) g[e] += t[e];
   }
@@ -191,12 +215,15 @@ __global__ __launch_bounds__(NTHR) void in_bwd_partial_kernel(DView x, const flo
     rstd[e] = stats[((int64_t)b * x.C + L.cl * N + e) * 2 + 1];
     s1[e] = s2[e] = 0.f;
   }
+  int yy, xx; pixel_yx(p0 + L.rl, x.W, yy, xx);
+  Off ox(x, b, yy, xx, L.RL, x.W), og(gy, b, yy, xx, L.RL, x.W), o2(has_g2 ? g2 : x, b, yy, xx, L.RL, x.W);
   for (int p = p0 + L.rl; p < p1; p += L.RL) {
-    int yy, xx; pixel_yx(p, x.W, yy, xx);
     float g[N], xh[N];
-    in_bwd_g<T>(x, mean, rstd, act, gy, fold, g2, has_g2, b, yy, xx, L.cl * N, g, xh);
+    in_bwd_g<T>(x, mean, rstd, act, gy, fold, g2, has_g2, b, yy, xx, L.cl * N, ox.o, og.o, o2.o, g, xh);
 #pragma unroll
     for (int e = 0; e < N; ++e) { s1[e] += g[e]; s2[e] += g[e] * xh[e]; }
+    const int wr = pixel_step(L.RL, x.W, yy, xx);
+    ox.advance(wr); og.advance(wr); o2.advance(wr);
   }
   __shared__ float sh[NTHR * 16];
 #pragma unroll
@@ -251,13 +278,16 @@ __global__ __launch_bounds__(NTHR) void in_bwd_apply_kernel(DView x, const float
     mean[e] = stats[2 * i]; rstd[e] = stats[2 * i + 1]; m1[e] = ws2[2 * i]; m2[e] = ws2[2 * i + 1];
   }
   T* dp = reinterpret_cast<T*>(dx.ptr);
+  int yy, xx; pixel_yx(p0 + L.rl, x.W, yy, xx);
+  Off ox(x, b, yy, xx, L.RL, x.W), og(gy, b, yy, xx, L.RL, x.W), o2(has_g2 ? g2 : x, b, yy, xx, L.RL, x.W), od(dx, b, yy, xx, L.RL, x.W);
   for (int p = p0 + L.rl; p < p1; p += L.RL) {
-    int yy, xx; pixel_yx(p, x.W, yy, xx);
     float g[N], xh[N];
-    in_bwd_g<T>(x, mean, rstd, act, gy, fold, g2, has_g2, b, yy, xx, L.cl * N, g, xh);
+    in_bwd_g<T>(x, mean, rstd, act, gy, fold, g2, has_g2, b, yy, xx, L.cl * N, ox.o, og.o, o2.o, g, xh);
 #pragma unroll
     for (int e = 0; e < N; ++e) { g[e] = rstd[e] * (g[e] - m1[e] - xh[e] * m2[e]); bs[e] += g[e]; }
-    Chunk<T>::store(dp + dx.pix(b, yy, xx) + L.cl * N, g);
+    Chunk<T>::store(dp + od.o + L.cl * N, g);
+    const int wr = pixel_step(L.RL, x.W, yy, xx);
+    ox.advance(wr); og.advance(wr); o2.advance(wr); od.advance(wr);
   }
   if (bias_part) {   // column sums of dx = gradient of the conv bias in front of this norm: partial per block
     __shared__ float sh[NTHR * 8];
@@ -301,23 +331,27 @@ __global__ __launch_bounds__(NTHR) void fold_add_kernel(DView a, int has_a, DVie
   const int b = blockIdx.y, HW = out.H * out.W;
   const int per = (HW + nblk - 1) / nblk, p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
   T* op = reinterpret_cast<T*>(out.ptr);
+  int yy, xx; pixel_yx(p0 + L.rl, out.W, yy, xx);
+  Off og(g, b, yy, xx, L.RL, out.W), oa(has_a ? a : g, b, yy, xx, L.RL, out.W), oy(act != GAN_ACT_NONE ? y : g, b, yy, xx, L.RL, out.W),
+      oo(out, b, yy, xx, L.RL, out.W);
   for (int p = p0 + L.rl; p < p1; p += L.RL) {
-    int yy, xx; pixel_yx(p, out.W, yy, xx);
     float v[N];
-    load_folded<T>(g, fold, b, yy, xx, L.cl * N, v);
+    load_folded<T>(g, fold, b, yy, xx, og.o, L.cl * N, v);
     if (has_a) {
       float t[N];
-      Chunk<T>::load(reinterpret_cast<const T*>(a.ptr) + a.pix(b, yy, xx) + L.cl * N, t);
+      Chunk<T>::load(reinterpret_cast<const T*>(a.ptr) + oa.o + L.cl * N, t);
 #pragma unroll
       for (int e = 0; e < N; ++e) v[e] += t[e];
     }
     if (act != GAN_ACT_NONE) {
       float t[N];
-      Chunk<T>::load(reinterpret_cast<const T*>(y.ptr) + y.pix(b, yy, xx) + L.cl * N, t);
+      Chunk<T>::load(reinterpret_cast<const T*>(y.ptr) + oy.o + L.cl * N, t);
 #pragma unroll
       for (int e = 0; e < N; ++e) v[e] *= act_grad_from_out(t[e], act);
     }
-    Chunk<T>::store(op + out.pix(b, yy, xx) + L.cl * N, v);
+    Chunk<T>::store(op + oo.o + L.cl * N, v);
+    const int wr = pixel_step(L.RL, out.W, yy, xx);
+    og.advance(wr); oa.advance(wr); oy.advance(wr); oo.advance(wr);
   }
 }
 

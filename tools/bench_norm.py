@@ -22,6 +22,8 @@ cases = {
     "in_apply  (read x, write y+halo)": ([ops.in_apply(x, stats, _lib.ACT_RELU, None, y, _lib.HALO_REFLECT)], 2),
     "in_apply+res (read x,res, write y)": ([ops.in_apply(x, stats, _lib.ACT_NONE, dx, y, _lib.HALO_REFLECT)], 3),
     "in_bwd fold (2x read x,gy, write dx)": ([ops.in_bwd(x, stats, _lib.ACT_RELU, gy, True, None, dx, ws)], 5),
+    "in_bwd nofold": ([ops.in_bwd(x, stats, _lib.ACT_RELU, gy, False, None, dx, ws)], 5),
+    "in_bwd nofold noact": ([ops.in_bwd(x, stats, _lib.ACT_NONE, gy, False, None, dx, ws)], 5),
     "in_bwd_bias fold": ([ops.in_bwd_bias(x, stats, _lib.ACT_RELU, gy, True, None, dx, ws, bg, Cc, False)], 5),
     "fold_add (read a,g, write out)": ([ops.fold_add(x, gy, True, dx)], 3),
 }
