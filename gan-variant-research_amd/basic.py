@@ -48,6 +48,12 @@ class ResnetGenerator(nn.Module):
             mult //= 2
         layers += _slots(1) + [nn.Conv2d(ngf, out_c, 7)] + _slots(1)
         self.net = nn.Sequential(*layers)
+        self.compute_dtype = F32
+
+    def forward(self, x):
+        """Basic_GAN/src/models.py:64-65 on the HIP kernels, differentiable (autograd.py)."""
+        from . import autograd as AG
+        return AG.generator_forward(self, x, "basic")
 
 
 class NLayerDiscriminator(nn.Module):
@@ -65,6 +71,12 @@ class NLayerDiscriminator(nn.Module):
             seq += [nn.Conv2d(ndf * prev, ndf * mult, 4, stride=2 if n < n_layers else 1, padding=1, bias=False)] + _slots(2)
         seq += [nn.Conv2d(ndf * mult, 1, 4, stride=1, padding=1)]
         self.net = nn.Sequential(*seq)
+        self.compute_dtype = F32
+
+    def forward(self, x):
+        """Basic_GAN/src/models.py:106-107 on the HIP kernels, differentiable (autograd.py)."""
+        from . import autograd as AG
+        return AG.discriminator_forward(self, x, "basic", "", self.ndf, self.n_layers)
 
 
 class GANLoss:

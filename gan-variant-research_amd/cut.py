@@ -70,21 +70,19 @@ class ResNetGenerator(nn.Module):
         self.upsample = nn.Sequential(*s)
         s = _slot(3); s[1] = nn.Conv2d(ngf, output_nc, 7)
         self.output = nn.Sequential(*s)
-        self._runner = None
+        self.compute_dtype = F32          # BF16: bf16 operands, fp32 accumulation (throughput mode)
 
-    def _run(self, x, layer_ids=None):
-        if self._runner is None or self._runner.key != (tuple(x.shape), x.device):
-            self._runner = _InferenceRunner(self, x)
-        return self._runner(x, layer_ids)
-
-    @torch.no_grad()
     def forward(self, x):
-        """(B,3,H,W) fp32 in [-1,1] -> (B,3,H,W) fp32; inference on the HIP kernels (training goes through CutTrainer)."""
-        return self._run(x)
+        """(B,3,H,W) fp32 in [-1,1] -> (B,3,H,W) fp32 on the HIP kernels, differentiable (autograd.py): one autograd node per call.
+        The fused CutTrainer is the fast training path; this is the drop-in nn.Module path."""
+        from . import autograd as AG
+        return AG.generator_forward(self, x, "cut")
 
-    @torch.no_grad()
     def get_feature_layers(self, x, layer_ids=None):
-        return self._run(x, list(NCE_LAYERS_DEFAULT) if layer_ids is None else list(layer_ids))
+        """generator_resnet_attn.py:190-235: numbered activations; ids beyond the last one are silently ignored there too."""
+        from . import autograd as AG
+        ids = feature_layers_present(list(NCE_LAYERS_DEFAULT) if layer_ids is None else list(layer_ids), self.n_blocks)
+        return AG.generator_forward(self, x, "cut", ids)
 
 
 class _PatchGANParams(nn.Module):
@@ -108,6 +106,12 @@ class MultiscaleDiscriminator(nn.Module):
             raise NotImplementedError("MI355X path implements the baseline config: num_scales=1, use_spectral_norm=False")
         self.input_nc, self.ndf, self.n_layers, self.num_scales = input_nc, ndf, n_layers, num_scales
         self.discriminators = nn.ModuleList([_PatchGANParams(input_nc, ndf, n_layers)])
+        self.compute_dtype = F32
+
+    def forward(self, x):
+        """discriminator_patchgan.py:102-116: list of per-scale logits (one scale), differentiable (autograd.py)."""
+        from . import autograd as AG
+        return [AG.discriminator_forward(self, x, "cut", "discriminators.0.model.", self.ndf, self.n_layers)]
 
 
 def build_models(config, device):
@@ -256,45 +260,6 @@ def feature_layers_present(layer_ids, n_blocks=9, n_down=2) -> List[int]:
     return [i for i in range(1 + n_down + n_blocks + n_down) if i in layer_ids]
 
 
-class _InferenceRunner:
-    """Forward-only generator program for ResNetGenerator.forward / get_feature_layers."""
-
-    def __init__(self, module: ResNetGenerator, x: torch.Tensor, dtype: int = F32):
-        assert x.is_cuda, "the MI355X path needs a GPU tensor (there is no CPU fallback)"
-        self.key = (tuple(x.shape), x.device)
-        B, _, H, W = x.shape
-        ops = HipOps(x.device)
-        self.ctx = Ctx(ops, x.device, dtype)
-        sd = {k: v.detach().float().contiguous() for k, v in module.state_dict().items()}
-        self.sd_src = module
-        self.params = {k: v.clone() for k, v in sd.items()}
-        grads = {k: torch.zeros_like(v) for k, v in self.params.items()}
-        self.net = GeneratorNet(self.ctx, self.params, grads, "cut", module.n_blocks, module.ngf, need_input_grad=False)
-        self.gpass = self.net.new_pass(B, H, W)
-        self.xin = torch.zeros(B, 3, H, W, dtype=torch.float32, device=x.device)
-        self.out = torch.zeros(B, 3, H, W, dtype=torch.float32, device=x.device)
-        fwd = self.gpass.fwd_program(self.xin)      # planning allocates the operand copies the repack must refresh
-        self.prog = Program("infer")
-        self.prog.add(self.net.repack_program())
-        self.prog.add(fwd)
-        self.prog.add(ops.view_to_nchw(self.gpass.img, 3, self.out))
-
-    def __call__(self, x, layer_ids):
-        for k, v in self.sd_src.state_dict().items():
-            self.params[k].copy_(v)
-        self.xin.copy_(x)
-        self.prog.run()
-        if layer_ids is None:
-            return self.out.clone()
-        feats = []
-        for i in feature_layers_present(layer_ids, self.net.n_blocks):
-            a = self.gpass.acts[i]
-            t = torch.zeros(a.B, a.C, a.H, a.W, dtype=torch.float32, device=x.device)
-            self.ctx.ops.view_to_nchw(a, a.C, t)()
-            feats.append(t)
-        return feats
-
-
 # ------------------------------------------------------------------------------------------------
 # the trainer
 # ------------------------------------------------------------------------------------------------
@@ -401,25 +366,8 @@ class CutTrainer:
         rp, c32, dnet = self.d_r1, self.ctx32, self.D32
         pr.add(ops.nchw_to_view(self.photos, 3, rp.x, HALO_ZERO))
         pr.add(rp.fwd_program())
-        lg = rp.logits
-        ones = dnet.gbuf("r1_ones", B, lg.H, lg.W, lg.C, 2)
-        n_log = B * lg.H * lg.W
-        pr.add(ops.patch_loss(lg, 2, 0.0, -float(n_log), self._slot("scratch"), ones))   # d(sum D)/dlogits = 1
-        deltas: List[View] = []
-        pr.add(rp.bwd_program(ones, wgrad=False, need_input_grad=True, keep=deltas))
-        u = c32.view(B, S, S, 8, 1)
         scale = cfg["r1"]["gamma"] * cfg["r1"]["every"]
-        pr.add(ops.r1_reduce(rp.g_input, 3, scale, self._slot("r1"), u, c32.scratch("r1_ws", 1024)))
-        # second-order pass: u_{i} = mask_i * (W_i * u_{i-1});  dW_i = wgrad(u_{i-1}, delta_i)
-        for li, conv in enumerate(dnet.convs):
-            delta = deltas[len(deltas) - 1 - li]
-            pr.add(conv.wgrad(u, delta, accumulate=False, bias_too=False))
-            if li == dnet.nconv - 1:
-                break
-            a = rp.acts[li]
-            nxt = c32.view(B, a.H, a.W, a.C, 1)
-            pr.add(conv.fwd(u, nxt, ACT_NONE, mask=a, use_bias=False))
-            u = nxt
+        pr.add(rp.r1_program(scale, self._slot("r1"), self._slot("scratch")))
         skip = []
         for li, conv in enumerate(dnet.convs):   # biases: zero grad except the last one, whose grad is None (skipped)
             if conv.grad_b is None:

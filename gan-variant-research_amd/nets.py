@@ -315,6 +315,33 @@ class DPass:
             xin = self.acts[li]
         return prog
 
+    def r1_program(self, scale: float, loss: torch.Tensor, scratch: torch.Tensor) -> Program:
+        """R1 penalty (train_cutpp.py:165-203) after this pass's forward: *loss = mean_b sum_chw (d sum D(x) / dx)^2 and the
+        weight gradients of scale * r1, as an explicit second-order program (no autograd graph):
+        first-order input gradient with the LeakyReLU masks fused in the dgrad epilogues (delta_i kept per layer), then the
+        linearised forward u_i = mask_i * (W_i * u_{i-1}) seeded with u_0 = scale * 2 g / B, with dW_i = wgrad(u_{i-1}, delta_i).
+        Bias gradients are zero except the last bias, whose gradient is None in the reference (the caller skips it)."""
+        net, ctx, ops, B = self.net, self.net.ctx, self.net.ctx.ops, self.B
+        assert net.style == "cut", "R1 is part of the CUT trainer (no norm layers in its discriminator)"
+        pr = Program("R1")
+        lg = self.logits
+        ones = net.gbuf("r1_ones", B, lg.H, lg.W, lg.C, 2)
+        pr.add(ops.patch_loss(lg, 2, 0.0, -float(B * lg.H * lg.W), scratch, ones))   # d(sum D)/dlogits = 1
+        deltas: List[View] = []
+        pr.add(self.bwd_program(ones, wgrad=False, need_input_grad=True, keep=deltas))
+        u = ctx.view(B, self.H, self.W, self.x.C, 1)
+        pr.add(ops.r1_reduce(self.g_input, net.in_c, scale, loss, u, ctx.scratch("r1_ws", 1024)))
+        for li, conv in enumerate(net.convs):
+            delta = deltas[len(deltas) - 1 - li]
+            pr.add(conv.wgrad(u, delta, accumulate=False, bias_too=False))
+            if li == net.nconv - 1:
+                break
+            a = self.acts[li]
+            nxt = ctx.view(B, a.H, a.W, a.C, 1)
+            pr.add(conv.fwd(u, nxt, ACT_NONE, mask=a, use_bias=False))
+            u = nxt
+        return pr
+
     def grad_logits_view(self) -> View:
         """Where the loss writes dL/dlogits: zero halo 2 (= k-1-p of the last 4x4 s1 p1 conv's input gradient)."""
         lg = self.logits

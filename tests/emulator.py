@@ -425,8 +425,9 @@ class EmuOps:
     def patchnce_bwd(self, tgt, ids, P, Cc, temperature, weight, gtgt, ws):
         def op():
             src = self._nce_src[ws.data_ptr()]
-            l, t, (ys, xs) = self._nce(src, tgt, ids, Cc, temperature)
-            (g,) = torch.autograd.grad(l * weight, t)
+            with torch.enable_grad():   # the op may run inside an autograd.Function.forward, where grad mode is off
+                l, t, (ys, xs) = self._nce(src, tgt, ids, Cc, temperature)
+                (g,) = torch.autograd.grad(l * weight, t)
             buf = gtgt.nhwc()
             acc = buf.float()
             for i in range(ids.numel()):

@@ -227,8 +227,10 @@ def test_generator_module_forward_and_features(golden):
     C.set_seed(42)
     gen, disc = C.build_models(cases.small_config(), DEV)
     x = torch.from_numpy(g["x64"]).to(DEV)
-    np.testing.assert_allclose(gen(x).cpu().numpy(), g["G64"], rtol=1e-3, atol=1e-3)
-    feats = gen.get_feature_layers(x, [0, 4, 8, 12, 16])
+    assert gen(x).requires_grad                     # the modules are differentiable nn.Modules now (autograd.py)
+    with torch.no_grad():
+        np.testing.assert_allclose(gen(x).cpu().numpy(), g["G64"], rtol=1e-3, atol=1e-3)
+        feats = gen.get_feature_layers(x, [0, 4, 8, 12, 16])
     assert len(feats) == 4
     for i, f in enumerate(feats):
         assert list(f.shape) == list(g[f"feat{i}.shape"])
@@ -242,3 +244,22 @@ def test_basic_gan_iterations_fp32_vs_oracle():
 
 def test_basic_gan_iterations_bf16_vs_oracle():
     cases.run_basic_iterations(DEV, HipOps(torch.device(DEV)), amp=True, S=64, B=2, niter=1, tol0=4e-2)
+
+
+# ---------------------------------------------------------------------------------------------- drop-in nn.Module / loss / optimiser API
+def test_autograd_bridge_hip():
+    """G(x), get_feature_layers, D(x), r1_regularization as differentiable nn.Module calls on the HIP kernels vs the oracle under autograd."""
+    from tests.test_autograd_bridge import bridge_cases
+    bridge_cases(DEV, 5e-4)
+
+
+def test_loss_callables_hip(monkeypatch):
+    from gan_variant_research_amd import losses as L
+    from tests.test_autograd_bridge import loss_cases
+    monkeypatch.setattr(L, "_PLANS", {})
+    loss_cases(DEV, 1e-4)
+
+
+def test_training_utilities_hip(tmp_path):
+    from tests.test_autograd_bridge import training_cases
+    training_cases(DEV, 1e-5, tmp_path)
