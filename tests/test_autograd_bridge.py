@@ -249,3 +249,47 @@ def training_cases(device, tol, tmp_path):
 def test_training_utilities_on_emulator(monkeypatch, tmp_path):
     monkeypatch.setattr(AG, "_OPS_FACTORY", lambda device: EmuOps())
     training_cases(torch.device("cpu"), 2e-6, tmp_path)
+
+
+def module_step_cases(device, tol0, tol1):
+    """The reference-shaped step driver on the module API (module_step.train_step) vs the oracle's train_step, steps 0 and 1,
+    DiffAugment on with injected draws: the same comparison tests/cases.py::run_cut_steps makes for the fused CutTrainer."""
+    from gan_variant_research_amd import losses as L, module_step as MS, training as T
+    from tests import cases
+    cfg = cases.small_config()
+    cfg["diffaugment"]["enable"] = True
+    B, S = 2, 32
+    C.set_seed(42)
+    gen, disc = C.build_models(cfg, "cpu")
+    gen, disc = gen.to(device), disc.to(device)
+    cut_ref.set_seed(42)
+    gp, dp = cut_ref.init_generator(), cut_ref.init_discriminator()
+    og, od = cut_ref.AdamState(gp), cut_ref.AdamState(dp)
+    ema_ref = {k: v.detach().clone() for k, v in gp.items()}
+    opt_G, opt_D = T.get_optimizer(gen, cfg["optim"]["G"]), T.get_optimizer(disc, cfg["optim"]["D"])
+    ema = T.EMA(gen, cfg["ema"]["decay"], optimizer=opt_G)
+    amp = T.AMPContext(False)
+    aug = L.DiffAugment(cfg["diffaugment"]["policy"])
+    g = torch.Generator().manual_seed(1234)
+    photos = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    monets = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    for step in range(2):
+        torch.manual_seed(9000 + step)
+        rnd = cut_ref.sample_step_randomness(B, S, S, use_aug=True)
+        ref = cut_ref.train_step(step, photos, monets, gp, dp, og, od, ema_ref, cfg, rnd)
+        rnd_dev = {k: ([t.to(device) for t in v] if k == "nce_ids" else v) for k, v in rnd.items()}
+        got = MS.train_step(step, photos.to(device), monets.to(device), gen, disc, opt_G, opt_D, ema, amp, aug, cfg, device, rnd=rnd_dev)
+        assert list(got) == list(ref)
+        for k in ref:
+            atol = max(tol0 * 0.1 if step == 0 else 2e-4, 1e-3 if k == "g_adv" else 0.0)
+            np.testing.assert_allclose(got[k], ref[k], rtol=tol0 if step == 0 else tol1, atol=atol, err_msg=f"step{step} {k}")
+    for k, v in gen.state_dict().items():          # parameters to 2*lr (Adam's sign-like first updates on zero gradients)
+        np.testing.assert_allclose(v.cpu().numpy(), gp[k].detach().numpy(), rtol=0, atol=1e-3, err_msg=k)
+
+
+def test_module_step_on_emulator(monkeypatch):
+    from gan_variant_research_amd import losses as L
+    monkeypatch.setattr(AG, "_OPS_FACTORY", lambda device: EmuOps())
+    monkeypatch.setattr(L, "_PLANS", {})
+    torch.set_num_threads(4)
+    module_step_cases(torch.device("cpu"), 2e-4, 2e-3)

@@ -263,3 +263,11 @@ def test_loss_callables_hip(monkeypatch):
 def test_training_utilities_hip(tmp_path):
     from tests.test_autograd_bridge import training_cases
     training_cases(DEV, 1e-5, tmp_path)
+
+
+def test_module_step_hip(monkeypatch):
+    """The reference's train_step, written against the drop-in module API, on the HIP kernels vs the oracle (steps 0-1, DiffAugment on)."""
+    from gan_variant_research_amd import losses as L
+    from tests.test_autograd_bridge import module_step_cases
+    monkeypatch.setattr(L, "_PLANS", {})
+    module_step_cases(DEV, 1e-3, 2e-3)
