@@ -232,6 +232,8 @@ class CycleGANTrainer:
         self.upd_g.run()
         self.prog_da.run(); self._allreduce(self.opt_DA); self.upd_da.run()
         self.prog_db.run(); self._allreduce(self.opt_DB); self.upd_db.run()
+        from .cut import _notify_weights_changed
+        _notify_weights_changed()
         if not sync:
             return None
         v = self.losses.tolist()

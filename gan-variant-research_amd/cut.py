@@ -37,6 +37,11 @@ def set_seed(seed: int):
 # ------------------------------------------------------------------------------------------------
 # parameter containers with the reference's module tree (so state_dict keys and init order match)
 # ------------------------------------------------------------------------------------------------
+def _notify_weights_changed():
+    from . import autograd as AG
+    AG.notify_weights_changed()
+
+
 def _slot(n):
     return [nn.Identity() for _ in range(n)]
 
@@ -242,6 +247,36 @@ class FusedAdam:
                                       self.ema_decay if self.ema_decay is not None else 0.0, self.norm_out, self.ws)
 
 
+def _adam_state_dict(opt: "FusedAdam") -> dict:
+    """torch.optim.Adam.state_dict() layout (what utils/io_ckpt.py:70-71 stores), parameters numbered in state_dict order."""
+    steps = opt.steps.cpu()
+    state = {}
+    for i, n in enumerate(opt.names):
+        o, sz = int(opt.offsets[i]), opt.sizes[i]
+        shp = opt.params[n].shape
+        state[i] = {"step": steps[i].float().reshape(()), "exp_avg": opt.flat_m[o:o + sz].view(shp).clone(),
+                    "exp_avg_sq": opt.flat_v[o:o + sz].view(shp).clone()}
+    group = {"lr": opt.lr, "betas": tuple(opt.betas), "eps": opt.eps, "weight_decay": 0.0, "amsgrad": False, "maximize": False, "foreach": None,
+             "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(opt.names)))}
+    return {"state": state, "param_groups": [group]}
+
+
+def _load_adam_state_dict(opt: "FusedAdam", sd: dict):
+    opt.flat_m.zero_(); opt.flat_v.zero_(); opt.steps.zero_()
+    steps = torch.zeros(len(opt.names), dtype=torch.int32)
+    for i, st in sd["state"].items():
+        i = int(i)
+        n = opt.names[i]
+        o, sz = int(opt.offsets[i]), opt.sizes[i]
+        opt.flat_m[o:o + sz].copy_(st["exp_avg"].reshape(-1))
+        opt.flat_v[o:o + sz].copy_(st["exp_avg_sq"].reshape(-1))
+        steps[i] = int(float(st["step"]))
+    opt.steps.copy_(steps)
+    g = sd["param_groups"][0]
+    if (g["lr"], tuple(g["betas"]), g["eps"]) != (opt.lr, tuple(opt.betas), opt.eps):
+        raise ValueError("checkpoint optimiser hyper-parameters differ from the trainer's config (they are baked into its programs)")
+
+
 def get_optimizer_config(opt_config: dict) -> dict:
     """sched_optim.py:16-18 defaults."""
     return {"lr": opt_config.get("lr", 2e-4), "betas": tuple(opt_config.get("betas", [0.5, 0.999])),
@@ -391,7 +426,10 @@ class CutTrainer:
             pg.add(ops.diffaug_bwd(dp.g_input, 3, self.prm["fake_g"], g_adv_img, ctx.scratch("aug_ws", B + 16)))
         else:
             g_adv_img = dp.g_input
-        first = True
+        # The generator's gradient block is cleared once and every pass ACCUMULATES into it: the feature pass (p2) stops at the last
+        # PatchNCE layer, so "first pass writes, later passes add" would leave the layers behind it (upsample.3, output.1) adding
+        # into the previous step's values.
+        pg.add(ops.zero_(self.opt_G.flat_g))
         g_img, g_fold, g_img2 = g_adv_img, False, None
         if self.nce_layers:
             pg.add(self.p2.fwd_program(self.p1.img))
@@ -410,10 +448,9 @@ class CutTrainer:
                         return [ops.patchnce_bwd(tgt, ids, P, tgt.C, cfg["patchnce"]["temperature"], wl, gv, ws)]
                     return hook
                 hooks[li] = mk()
-            pg.add(self.p2.bwd_program(hooks=hooks, accumulate=False, need_input_grad=True))
-            first = False
+            pg.add(self.p2.bwd_program(hooks=hooks, accumulate=True, need_input_grad=True))
             g_img, g_fold, g_img2 = self.p2.g_input, True, g_adv_img
-        pg.add(self.p1.bwd_program(g_img, g_fold, g_img2, accumulate=not first))
+        pg.add(self.p1.bwd_program(g_img, g_fold, g_img2, accumulate=True))
         self.prog_g_compute = pg
         # identity (identity_l1.py:6-22): third pass, gradient scaled by the device-resident identity weight
         pi = Program("G-identity")
@@ -494,6 +531,7 @@ class CutTrainer:
             self.prog_g_identity.run()
         self._allreduce(self.opt_G)
         self.prog_g_update.run()
+        _notify_weights_changed()          # parameters changed through raw pointers: module-level bridges repack on next use
         if not sync:
             return None
         v = self.losses.tolist()
@@ -508,6 +546,43 @@ class CutTrainer:
         """G(photos) of the last step as (B,3,H,W) fp32."""
         self.prog_fake_out.run()
         return self.fake_out
+
+    # ------------------------------------------------------------------ checkpoints (utils/io_ckpt.py:56-118, SURVEY §8f-1)
+    def checkpoint(self, step: int, metrics: Optional[dict] = None) -> dict:
+        """The reference's checkpoint dict: generator / discriminator state_dicts (reference keys), torch.optim.Adam-layout optimiser
+        states, {'decay','shadow'} EMA -- loadable by the reference's load_checkpoint and vice versa."""
+        return {"step": step, "generator": {k: v.clone() for k, v in self.generator.state_dict().items()},
+                "discriminator": {k: v.clone() for k, v in self.discriminator.state_dict().items()},
+                "opt_G": _adam_state_dict(self.opt_G), "opt_D": _adam_state_dict(self.opt_D), "metrics": metrics or {}, "config": self.config,
+                "ema_G": {"decay": self.opt_G.ema_decay, "shadow": {k: v.clone() for k, v in self.opt_G.shadow.items()}}, "scaler": {}}
+
+    def save_checkpoint(self, path: str, step: int, metrics: Optional[dict] = None):
+        import pathlib
+        pathlib.Path(path).parent.mkdir(parents=True, exist_ok=True)
+        torch.save(self.checkpoint(step, metrics), path)
+
+    def load_checkpoint(self, path_or_dict) -> dict:
+        """Resume (train_cutpp.py:372-397): weights, Adam moments and step counts, EMA shadow; then refresh the operand copies.
+        Files are read with weights_only=True (tensors and plain containers only)."""
+        ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location=self.device, weights_only=True)
+        for mod, opt, key in ((self.generator, self.opt_G, "generator"), (self.discriminator, self.opt_D, "discriminator")):
+            missing = set(opt.params) ^ set(ck[key])
+            if missing:
+                raise KeyError(f"checkpoint['{key}'] keys differ from the model's: {sorted(missing)[:4]} ...")
+            for k, v in ck[key].items():
+                opt.params[k].copy_(v)
+        if "opt_G" in ck:
+            _load_adam_state_dict(self.opt_G, ck["opt_G"])
+        if "opt_D" in ck:
+            _load_adam_state_dict(self.opt_D, ck["opt_D"])
+        if "ema_G" in ck and self.opt_G.flat_ema is not None:
+            for k, v in ck["ema_G"]["shadow"].items():
+                self.opt_G.shadow[k].copy_(v)
+        self.G.repack_program().run()
+        self.D.repack_program().run()
+        from . import autograd as AG
+        AG.notify_weights_changed()
+        return ck
 
     def ema_state_dict(self):
         return {"decay": self.opt_G.ema_decay, "shadow": {k: v.clone() for k, v in self.opt_G.shadow.items()}}

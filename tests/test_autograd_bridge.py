@@ -293,3 +293,36 @@ def test_module_step_on_emulator(monkeypatch):
     monkeypatch.setattr(L, "_PLANS", {})
     torch.set_num_threads(4)
     module_step_cases(torch.device("cpu"), 2e-4, 2e-3)
+
+
+def test_fused_trainer_matches_module_step_over_three_steps(monkeypatch):
+    """Two independent drivers of the same step -- the fused CutTrainer programs and the reference-shaped module-API step -- must agree
+    beyond the two steps the golden vectors pin (catches state carried wrongly from one step to the next, e.g. gradient blocks)."""
+    from gan_variant_research_amd import losses as L, module_step as MS, training as T
+    from tests import cases
+    monkeypatch.setattr(AG, "_OPS_FACTORY", lambda device: EmuOps())
+    monkeypatch.setattr(L, "_PLANS", {})
+    torch.set_num_threads(4)
+    cfg = cases.small_config()
+    cfg["diffaugment"]["enable"] = True
+    B, S = 2, 32
+    C.set_seed(42)
+    gen, disc = C.build_models(cfg, "cpu")
+    tr = C.CutTrainer(gen, disc, cfg, B, S, device="cpu", amp=False, ops=EmuOps())
+    C.set_seed(42)
+    gen2, disc2 = C.build_models(cfg, "cpu")
+    opt_G, opt_D = T.get_optimizer(gen2, cfg["optim"]["G"]), T.get_optimizer(disc2, cfg["optim"]["D"])
+    ema, amp, aug = T.EMA(gen2, cfg["ema"]["decay"], optimizer=opt_G), T.AMPContext(False), L.DiffAugment(cfg["diffaugment"]["policy"])
+    g = torch.Generator().manual_seed(1234)
+    photos, monets = torch.rand(B, 3, S, S, generator=g) * 2 - 1, torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    for step in range(3):
+        torch.manual_seed(9000 + step)
+        rnd = cut_ref.sample_step_randomness(B, S, S, use_aug=True)
+        torch.manual_seed(9000 + step)
+        rnd_tr = tr.sample_randomness()
+        a = tr.train_step(step, photos, monets, rnd_tr)
+        b = MS.train_step(step, photos, monets, gen2, disc2, opt_G, opt_D, ema, amp, aug, cfg, torch.device("cpu"), rnd=rnd)
+        for k in a:
+            np.testing.assert_allclose(a[k], b[k], rtol=2e-3, atol=1e-3 if k == "g_adv" else 2e-4, err_msg=f"step {step} {k}")
+    worst = max(float((tr.opt_G.params[k] - v.data).abs().max()) for k, v in gen2.named_parameters() if not k.endswith(".bias"))
+    assert worst < 6e-4, worst      # three sign-like Adam steps of lr 2e-4
