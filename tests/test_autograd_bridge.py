@@ -326,3 +326,31 @@ def test_fused_trainer_matches_module_step_over_three_steps(monkeypatch):
             np.testing.assert_allclose(a[k], b[k], rtol=2e-3, atol=1e-3 if k == "g_adv" else 2e-4, err_msg=f"step {step} {k}")
     worst = max(float((tr.opt_G.params[k] - v.data).abs().max()) for k, v in gen2.named_parameters() if not k.endswith(".bias"))
     assert worst < 6e-4, worst      # three sign-like Adam steps of lr 2e-4
+
+
+def test_inference_path_on_emulator(monkeypatch, tmp_path):
+    """inference.py (generate_folder.py): EMA weights are preferred, uint8 conversion, folder round trip through PIL."""
+    from gan_variant_research_amd import inference as I
+    monkeypatch.setattr(AG, "_OPS_FACTORY", lambda device: EmuOps())
+    torch.manual_seed(3)
+    G = C.ResNetGenerator(3, 3, ngf=8, n_blocks=2)
+    shadow = {k: v.detach() * 0.5 for k, v in G.state_dict().items()}
+    ck = tmp_path / "ckpt_final.pt"
+    torch.save({"step": 7, "generator": G.state_dict(), "ema_G": {"decay": 0.999, "shadow": shadow}, "config": {}}, ck)
+    G2 = I.load_generator(str(ck), device="cpu", ngf=8, n_blocks=2, bf16=False)
+    for k, v in G2.state_dict().items():
+        assert torch.equal(v, shadow[k]), k                      # EMA weights win over 'generator'
+    assert I.pick_state_dict({"G_ema": {"w": torch.zeros(1)}}) == {"w": torch.zeros(1)}
+    x = torch.rand(2, 3, 16, 16) * 2 - 1
+    u8 = I.stylize(G2, x)
+    want = cut_ref.generator_forward({k: v for k, v in shadow.items()}, x, n_blocks=2)
+    want = (want.clamp(-1, 1) * 0.5 + 0.5).mul(255).round()
+    assert u8.dtype == torch.uint8 and int((u8.float() - want).abs().max()) <= 1
+    from PIL import Image
+    src = tmp_path / "photos" / "sub"
+    src.mkdir(parents=True)
+    for i in range(3):
+        Image.fromarray((torch.rand(20, 24, 3) * 255).byte().numpy()).save(src / f"p{i}.png")
+    n = I.stylize_folder(G2, str(tmp_path / "photos"), str(tmp_path / "out"), device="cpu", img_size=16, batch=2)
+    outs = sorted((tmp_path / "out" / "sub").glob("*.jpg"))
+    assert n == 3 and len(outs) == 3 and Image.open(outs[0]).size == (16, 16)
