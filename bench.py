@@ -180,9 +180,13 @@ def main():
         step += 1
     barrier()
     t0 = time.perf_counter()
+    # sync="lag": each step's loss dict (and NaN check) is delivered one call later, so the read-back of step k overlaps the
+    # queueing of step k+1; flush_losses() inside the timed region collects the last one -- all K dicts are produced in the window
     for _ in range(args.steps):
-        last = tr.train_step(step, photos, monets, tr.sample_randomness(aug_gen, nce_gen))
+        r = tr.train_step(step, photos, monets, tr.sample_randomness(aug_gen, nce_gen), sync="lag")
+        last = r if r is not None else last
         step += 1
+    last = tr.flush_losses() or last
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -206,7 +210,7 @@ def main():
         }
         out["roofline"] = dominant_kernel_roofline(tr)
         print(f"[bench] gpu: {ips:.1f} images/s, {dt / args.steps * 1e3:.2f} ms/step; roofline {out['roofline']['achieved']} TFLOP/s", file=sys.stderr, flush=True)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # the CPU baseline is reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -505,8 +505,9 @@ class CutTrainer:
 
     # ------------------------------------------------------------------ the step
     def train_step(self, step: int, photos: torch.Tensor, monets: torch.Tensor, rnd: Optional[dict] = None, sync: bool = True):
-        """One iteration; returns the reference's loss dict (train_cutpp.py:315-323).  sync=False skips the loss read-back
-        (and the NaN check) and returns None."""
+        """One iteration; returns the reference's loss dict (train_cutpp.py:315-323).  sync=True reads the losses back before
+        returning (the reference's .item() calls); sync="lag" returns the PREVIOUS step's dict (see flush_losses); sync=False skips
+        the read-back and the NaN check and returns None."""
         cfg = self.config
         lw = cfg["loss_weights"]
         idw = identity_weight_at(step, cfg)
@@ -532,15 +533,49 @@ class CutTrainer:
         self._allreduce(self.opt_G)
         self.prog_g_update.run()
         _notify_weights_changed()          # parameters changed through raw pointers: module-level bridges repack on next use
-        if not sync:
+        if sync is False:
             return None
-        v = self.losses.tolist()
+        meta = (step, idw, do_r1)
+        if sync == "lag":
+            # the read-back of this step's losses is queued behind its kernels and collected when the NEXT step has been queued:
+            # every step's dict is still delivered and NaN-checked, one call late, and the host never idles the GPU (-2 % step time)
+            prev = self._collect_losses()
+            if self._pinned is None:
+                self._pinned = [torch.zeros(16, dtype=torch.float32, pin_memory=self.device.type == "cuda") for _ in range(2)]
+                self._events = [torch.cuda.Event() if self.device.type == "cuda" else None for _ in range(2)]
+            i = step & 1
+            self._pinned[i].copy_(self.losses, non_blocking=True)
+            if self._events[i] is not None:
+                self._events[i].record()
+            self._pending = (i, meta)
+            return prev
+        return self._loss_dict(self.losses.tolist(), meta)
+
+    _pinned, _events, _pending = None, None, None
+
+    def _loss_dict(self, v, meta) -> dict:
+        step, idw, do_r1 = meta
+        lw = self.config["loss_weights"]
         out = {"d_loss": v[0] + v[1], "g_adv": v[3] / lw["adv"] if lw["adv"] != 0 else 0.0, "nce": v[4] / lw["patchnce"] if lw["patchnce"] > 0 else 0.0,
                "identity": v[5] if idw > 0 else 0.0, "r1": v[2] if do_r1 else 0.0, "identity_weight": idw}
         out["g_loss"] = lw["adv"] * out["g_adv"] + lw["patchnce"] * out["nce"] + idw * out["identity"]
         if any(not math.isfinite(x) for k, x in out.items() if k != "identity_weight"):
             raise ValueError(f"NaN loss detected at step {step}. Training stopped to prevent corruption.")   # train_cutpp.py:326-329
         return out
+
+    def _collect_losses(self) -> Optional[dict]:
+        """Loss dict of the step whose read-back is pending (sync="lag"), or None."""
+        if self._pending is None:
+            return None
+        i, meta = self._pending
+        self._pending = None
+        if self._events[i] is not None:
+            self._events[i].synchronize()
+        return self._loss_dict(self._pinned[i].tolist(), meta)
+
+    def flush_losses(self) -> Optional[dict]:
+        """With sync="lag": waits for and returns the last queued step's losses."""
+        return self._collect_losses()
 
     def generated(self) -> torch.Tensor:
         """G(photos) of the last step as (B,3,H,W) fp32."""

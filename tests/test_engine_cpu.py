@@ -95,3 +95,25 @@ def test_cut_trainer_checkpoint_round_trip(tmp_path):
         assert torch.equal(v, b.opt_G.params[k]), k
     for k, v in a.ema_state_dict()["shadow"].items():
         assert torch.equal(v, b.ema_state_dict()["shadow"][k]), k
+
+
+def test_lagged_loss_readback_delivers_every_step():
+    """train_step(sync="lag") returns the previous step's dict; the values equal the synchronous ones."""
+    cfg = cases.small_config()
+    B, S = 2, 32
+
+    def make():
+        C.set_seed(42)
+        gen, disc = C.build_models(cfg, "cpu")
+        return C.CutTrainer(gen, disc, cfg, B, S, device="cpu", amp=False, ops=EmuOps())
+    g = torch.Generator().manual_seed(5)
+    photos, monets = torch.rand(B, 3, S, S, generator=g) * 2 - 1, torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    a, b = make(), make()
+    rnds = []
+    for step in range(3):
+        torch.manual_seed(100 + step)
+        rnds.append(a.sample_randomness())
+    want = [a.train_step(s, photos, monets, rnds[s]) for s in range(3)]
+    got = [b.train_step(s, photos, monets, rnds[s], sync="lag") for s in range(3)]
+    assert got[0] is None and got[1] == want[0] and got[2] == want[1]
+    assert b.flush_losses() == want[2] and b.flush_losses() is None
