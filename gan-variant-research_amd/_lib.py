@@ -59,6 +59,8 @@ PROTOTYPES = {
     "gan_wgrad_patch_splits": (C.c_int, [PW]),
     "gan_wgrad_reduce": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "gan_conv_patch_ok": (C.c_int, [PC]),
+    "gan_conv_stats_parts": (C.c_int, [PC]),
+    "gan_in_stats_from_parts": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp]),
     "gan_pack_weight": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "gan_pack_weight_batch": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "gan_bias_grad": (C.c_int, [PV, C.c_int, vp, C.c_int, vp, vp]),

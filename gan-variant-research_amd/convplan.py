@@ -8,6 +8,8 @@ discriminator_patchgan.py:27-51; Basic_GAN/src/models.py:12-103) lives here; the
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional, Tuple
 
 import torch
@@ -152,17 +154,26 @@ class ConvLayer:
         return out
 
     # ------------------------------------------------------------------ forward
-    def fwd(self, x: View, y: View, act: int = ACT_NONE, mask: Optional[View] = None, use_bias: bool = True):
+    def fwd(self, x: View, y: View, act: int = ACT_NONE, mask: Optional[View] = None, use_bias: bool = True,
+            stats_ws: Optional[torch.Tensor] = None):
+        """Forward launches.  stats_ws: if given and the launch can, its epilogue also writes the InstanceNorm partials of `y`
+        there; self.stats_parts then holds their count per image (0: not fused, the caller runs in_stats)."""
         assert x.C == cpad(self.cin) and y.C == cpad(self.cout) and x.B == y.B, (x.C, self.cin, y.C, self.cout)
         ops = self.ctx.ops
+        self.stats_parts = 0
         if not self.transposed:
             k, s, p = self.k, self.s, self.p
             ho, wo = (x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1
             assert (ho, wo) == (y.H, y.W) and x.halo >= p, (ho, wo, y.H, y.W, x.halo, p)
             pk = self.fwd_pack
-            return [ops.conv_igemm(pk.finalize(ConvCall(x.B, ho, wo, pk.cred, pk.ntaps, pk.nw, min(pk.nw, y.C), x, x.halo - p, x.halo - p, s, s,
-                                            pk.tapoff(x.Wp), None, self.bias_k if use_bias else None, y, y.halo, y.halo, 1, 1, act, mask,
-                                            mask.halo if mask else 0, mask.halo if mask else 0, pk.max_tapoff(x.Wp))))]
+            call = pk.finalize(ConvCall(x.B, ho, wo, pk.cred, pk.ntaps, pk.nw, min(pk.nw, y.C), x, x.halo - p, x.halo - p, s, s,
+                                        pk.tapoff(x.Wp), None, self.bias_k if use_bias else None, y, y.halo, y.halo, 1, 1, act, mask,
+                                        mask.halo if mask else 0, mask.halo if mask else 0, pk.max_tapoff(x.Wp)))
+            if stats_ws is not None and call.w_frag and call.Nst == y.C and not os.environ.get("GAN_NO_FUSED_STATS"):
+                n = ops.conv_stats_parts(call)
+                if 0 < n and x.B * n * y.C * 2 <= stats_ws.numel():
+                    call.stats, self.stats_parts = stats_ws, n
+            return [ops.conv_igemm(call)]
         assert (y.H, y.W) == (2 * x.H, 2 * x.W)
         return self._phased(self.fwd_packs, x, y, act, self.bias_k if use_bias else None, mask)
 

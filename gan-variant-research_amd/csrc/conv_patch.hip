@@ -33,6 +33,7 @@ struct PatchArgs {
   int Nst, act;
   int mask_Hp, mask_Wp, mask_y0, mask_x0;
   int w_bytes;
+  float* stats;                 // optional per-tile InstanceNorm partials [B][MT_img][out_C][2] (sum, sum of squares), plain stores
   unsigned long long* stamps;   // diagnostic build only (GAN_PATCH_STAMPS): [block][32] s_memtime stamps of wave 0
 };
 
@@ -47,9 +48,22 @@ constexpr int BN = 128, NTHR = 512;   // the tile height BM is a template parame
 constexpr int RMAX = 448;                    // pixels per patch buffer (7 slices of 64)
 constexpr int NSLICE = RMAX / 64;
 constexpr int PATCHB = RMAX * 128;
-constexpr int LDS_BYTES = 2 * PATCHB + 512;
+constexpr int STATS_LDS = 8 * 128 * 2 * 4;    // per-wave (sum, sumsq) of up to 128 channels, combined across the pixel-split waves
+constexpr int LDS_BYTES = 2 * PATCHB + 512 + STATS_LDS;
 
 struct TileGeo { int b, m0, n0, P0; };
+
+// sum over the 16 lanes of a DPP row (every lane ends with the total): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float row16_sum(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});
+  v += dpp(v, std::integral_constant<int, 0x4E>{});
+  v += dpp(v, std::integral_constant<int, 0x141>{});
+  v += dpp(v, std::integral_constant<int, 0x140>{});
+  return v;
+}
 
 __device__ __forceinline__ int pixbase(const PatchArgs& a, int b, int m) {
   const int ho = m / a.Wo, wo = m - ho * a.Wo;
@@ -75,6 +89,7 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   char* pbuf = lds;                       // [2][PATCHB]
   int32_t* taptab = reinterpret_cast<int32_t*>(lds + 2 * PATCHB);
+  float* stsh = reinterpret_cast<float*>(lds + 2 * PATCHB + 512);   // [8 waves][16*FJ channels][2]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < a.ntaps; i += NTHR) taptab[i] = a.tapoff[i] / a.Cin;   // pixel offsets
@@ -322,9 +337,15 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
 
     // ---- epilogue (the next tile's slab is in LDS and its first weights are in flight).  Specialised on the activation at
     // compile time: with a run-time switch per value the 64 results per lane made this phase VALU-bound (8.4k cycles).
-    auto epilogue = [&](auto act_tag, auto mask_tag) {
+    auto epilogue = [&](auto act_tag, auto mask_tag, auto stats_tag) {
       constexpr int ACT = decltype(act_tag)::value;
       constexpr bool MASK = decltype(mask_tag)::value;
+      constexpr bool STATS = decltype(stats_tag)::value;
+      float ssum[STATS ? 4 * FJ : 1], ssq[STATS ? 4 * FJ : 1];
+      if constexpr (STATS) {
+#pragma unroll
+        for (int q = 0; q < 4 * FJ; ++q) ssum[q] = ssq[q] = 0.f;
+      }
       bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
       const bf16_t* mask = reinterpret_cast<const bf16_t*>(a.mask);
       f32x4_t bq[FJ];   // bias of this lane's channel quads
@@ -348,6 +369,7 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float t = acc[i][j][e] + bq[j][e];
+            if constexpr (STATS) { const float tm = mok ? t : 0.f; ssum[4 * j + e] += tm; ssq[4 * j + e] += tm * tm; }
             v[e] = ACT == GAN_ACT_RELU ? fmaxf(t, 0.f) : ACT == GAN_ACT_LRELU ? (t > 0.f ? t : 0.2f * t) : ACT == GAN_ACT_TANH ? tanhf(t) : t;
           }
           if (MASK) {
@@ -375,13 +397,44 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
           if (mok && nst < a.Nst) *reinterpret_cast<u32x4_t*>(out + ob + nst) = st;
         }
       }
+      if constexpr (STATS) {
+        // InstanceNorm partials of this tile: over the 16 pixel lanes of a lane group, then over the pixel-split waves in a
+        // fixed order (deterministic: no atomics), one float2 per channel to stats[b][m-tile][n]
+        // row (16-lane) all-reduce with DPP modifiers on the adds -- vector ALU only; __shfl_xor lowers to ds_bpermute and 256 of
+        // those per wave cost 8 us per launch, as much as the statistics pass they replace
+#pragma unroll
+        for (int q = 0; q < 4 * FJ; ++q) { ssum[q] = row16_sum(ssum[q]); ssq[q] = row16_sum(ssq[q]); }
+        if (fr == 0) {
+#pragma unroll
+          for (int q = 0; q < 4 * FJ; ++q) {
+            const int ch = (q >> 2) * 16 + fg * 4 + (q & 3);           // channel inside this wave's 16*FJ
+            *reinterpret_cast<float2*>(stsh + ((wave * (16 * FJ) + ch) << 1)) = make_float2(ssum[q], ssq[q]);
+          }
+        }
+        __syncthreads();
+        constexpr int WM = 8 / WGN;
+        if (tid < BN) {
+          const int cwn = tid / (16 * FJ), cch = tid % (16 * FJ);
+          float2 tot = make_float2(0.f, 0.f);
+#pragma unroll
+          for (int m = 0; m < WM; ++m) {
+            const float2 v2 = *reinterpret_cast<const float2*>(stsh + (((m * WGN + cwn) * (16 * FJ) + cch) << 1));
+            tot.x += v2.x; tot.y += v2.y;
+          }
+          const int n = g.n0 + tid;
+          if (n < a.Nst)
+            *reinterpret_cast<float2*>(a.stats + (((int64_t)g.b * a.MT_img + g.m0 / BM) * a.out_C + n) * 2) = tot;
+        }
+        __syncthreads();   // stsh is rewritten by the next tile
+      }
     };
     using std::integral_constant;
-    if (a.mask) epilogue(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, true>{});   // LeakyReLU' masks only follow plain dgrads
-    else if (a.act == GAN_ACT_NONE) epilogue(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, false>{});
-    else if (a.act == GAN_ACT_LRELU) epilogue(integral_constant<int, GAN_ACT_LRELU>{}, integral_constant<bool, false>{});
-    else if (a.act == GAN_ACT_RELU) epilogue(integral_constant<int, GAN_ACT_RELU>{}, integral_constant<bool, false>{});
-    else epilogue(integral_constant<int, GAN_ACT_TANH>{}, integral_constant<bool, false>{});
+    if (a.mask) epilogue(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, true>{}, integral_constant<bool, false>{});   // LeakyReLU' masks only follow plain dgrads
+    else if (a.act == GAN_ACT_NONE && a.stats) epilogue(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, false>{}, integral_constant<bool, true>{});
+    else if (a.act == GAN_ACT_NONE) epilogue(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
+    else if (a.act == GAN_ACT_LRELU) epilogue(integral_constant<int, GAN_ACT_LRELU>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
+    else if (a.act == GAN_ACT_RELU) epilogue(integral_constant<int, GAN_ACT_RELU>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
+    else epilogue(integral_constant<int, GAN_ACT_TANH>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
 
     stamp();
     if (!has_next) break;
@@ -402,6 +455,21 @@ static int patch_span(const gan_conv_desc* d, int BM) {
   return (rows - 1) * d->in_sx + wraps * (jump > 0 ? jump : 0) + maxtap + 1;
 }
 
+// tile height: the one that needs the fewest CU-rounds x rows (GAN_PATCH_BM forces one; tuning aid, read per call so a test can toggle it)
+static int patch_tile_rows(const gan_conv_desc* d) {
+  const int M_img = d->Ho * d->Wo, ncu = 256;
+  int BM = 0, forced = 0;
+  int64_t best = 0;
+  { const char* e = getenv("GAN_PATCH_BM"); forced = e ? atoi(e) : 0; }
+  for (int cand : {256, 288}) {
+    if (patch_span(d, cand) > RMAX || (forced && forced != cand && patch_span(d, forced) <= RMAX)) continue;
+    const int64_t tiles = (int64_t)d->B * ((M_img + cand - 1) / cand) * ((d->Nst + BN - 1) / BN);
+    const int64_t cost = ((tiles + ncu - 1) / ncu) * cand;
+    if (!BM || cost < best) { BM = cand; best = cost; }
+  }
+  return BM;
+}
+
 // Pure predicate (no device access): does this descriptor qualify for the range-patch kernel?  The planner asks at
 // build time because qualifying calls need the fragment-major weight packing (gan_pack_weight layout 1).
 extern "C" int gan_conv_patch_ok(const gan_conv_desc* d) {
@@ -414,22 +482,19 @@ extern "C" int gan_conv_patch_ok(const gan_conv_desc* d) {
   return patch_span(d, 256) <= RMAX || patch_span(d, 288) <= RMAX ? 1 : 0;
 }
 
+// InstanceNorm partials per image the range-patch kernel writes to d->stats ([B][parts][out_C][2]); 0: this descriptor cannot fuse them
+extern "C" int gan_conv_stats_parts(const gan_conv_desc* d) {
+  if (!gan_conv_patch_ok(d) || d->act != GAN_ACT_NONE || d->mask || d->out_sy != 1 || d->out_sx != 1) return 0;
+  const int BM = patch_tile_rows(d);
+  return (d->Ho * d->Wo + BM - 1) / BM;
+}
+
 int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   if (!gan_conv_patch_ok(d)) return gan_set_error(-1, "conv: w_layout=1 (fragment-major weights) but the descriptor does not qualify for the range-patch kernel");
   PatchArgs a;
   const int M_img = d->Ho * d->Wo;
   const int ncu = 256;
-  // tile height: the one that needs the fewest CU-rounds x rows (GAN_PATCH_BM forces one; tuning aid)
-  int BM = 0;
-  int64_t best = 0;
-  int forced = 0;
-  { const char* e = getenv("GAN_PATCH_BM"); forced = e ? atoi(e) : 0; }   // read per launch so a test can toggle it
-  for (int cand : {256, 288}) {
-    if (patch_span(d, cand) > RMAX || (forced && forced != cand && patch_span(d, forced) <= RMAX)) continue;
-    const int64_t tiles = (int64_t)d->B * ((M_img + cand - 1) / cand) * ((d->Nst + BN - 1) / BN);
-    const int64_t cost = ((tiles + ncu - 1) / ncu) * cand;
-    if (!BM || cost < best) { BM = cand; best = cost; }
-  }
+  const int BM = patch_tile_rows(d);
   a.in = (const char*)d->in; a.w = (const char*)d->w; a.bias = d->bias; a.out = (char*)d->out; a.mask = (const char*)d->mask; a.tapoff = d->tapoff;
   a.B = d->B; a.M_img = M_img; a.Wo = d->Wo; a.MT_img = (M_img + BM - 1) / BM; a.NTILES = (d->Nst + BN - 1) / BN;
   a.tiles = a.B * a.MT_img * a.NTILES;
@@ -438,7 +503,8 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   a.in_Hp = d->in_Hp; a.in_Wp = d->in_Wp; a.in_y0 = d->in_y0; a.in_x0 = d->in_x0; a.in_sy = d->in_sy; a.in_sx = d->in_sx;
   a.in_pix = d->B * d->in_Hp * d->in_Wp;
   a.out_Hp = d->out_Hp; a.out_Wp = d->out_Wp; a.out_C = d->out_C; a.out_y0 = d->out_y0; a.out_x0 = d->out_x0; a.out_sy = d->out_sy; a.out_sx = d->out_sx;
-  a.Nst = d->Nst; a.act = d->act;
+  a.Nst = d->Nst; a.act = d->act; a.stats = d->stats;
+  if (d->stats && (d->act != GAN_ACT_NONE || d->mask)) return gan_set_error(-1, "conv: fused statistics need act = none and no mask");
   a.mask_Hp = d->mask_Hp; a.mask_Wp = d->mask_Wp; a.mask_y0 = d->mask_y0; a.mask_x0 = d->mask_x0;
   { const char* e = getenv("GAN_PATCH_STAMPS"); a.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
   const int grid = a.tiles < ncu ? a.tiles : ncu;

@@ -473,6 +473,15 @@ extern "C" int gan_in_stats(const gan_view* x, float eps, float* stats, float* w
   return 0;
 }
 
+// (mean, rstd) from per-tile partials written by a convolution epilogue (gan_conv_desc.stats): parts = fp32 [B][nparts][C][2]
+extern "C" int gan_in_stats_from_parts(const float* parts, int nparts, int B, int C, int HW, float eps, float* stats, void* stream) {
+  GAN_CHECK(parts && stats && nparts > 0 && B > 0 && C > 0 && HW > 0, "in_stats_from_parts: bad arguments");
+  const int BC = B * C;
+  hipLaunchKernelGGL(in_finalize_kernel, dim3((BC + 31) / 32), dim3(256), 0, (hipStream_t)stream, parts, nparts, C, BC, HW, eps, stats);
+  GAN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int gan_in_finalize(float* stats, int BC, int HW, float eps, void* stream) {
   GAN_CHECK(stats && BC > 0 && HW > 0, "in_finalize: bad arguments");
   hipLaunchKernelGGL(in_finalize_inplace_kernel, dim3((BC + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, BC, HW, eps);

@@ -135,9 +135,12 @@ class GPass:
         else:
             prog.add(ops.nchw_to_view(src, net.in_c, self.x0, HALO_REFLECT))
 
-        def norm(i, raw, stats, act, residual=None, out=None):
+        def norm(i, raw, stats, act, residual=None, out=None, conv=None):
             out = self.acts[i] if out is None else out
-            prog.add(ops.in_stats(raw, IN_EPS, stats, net.in_ws(self.B, raw.C)))
+            if conv is not None and conv.stats_parts:     # the convolution's epilogue already wrote per-tile (sum, sum of squares)
+                prog.add(ops.in_stats_from_parts(net.in_ws(self.B, raw.C), conv.stats_parts, self.B, raw.C, raw.H * raw.W, IN_EPS, stats))
+            else:
+                prog.add(ops.in_stats(raw, IN_EPS, stats, net.in_ws(self.B, raw.C)))
             prog.add(ops.in_apply(raw, stats, act, residual, out, self.halo_mode(i) if out is self.acts[i] else HALO_REFLECT))
 
         prog.add(net.c_init.fwd(self.x0, self.raw[0]))
@@ -154,10 +157,10 @@ class GPass:
             ca, cb = net.c_blk[k]
             ra, rb = self.raw[i]
             sa, sb = self.stats[i]
-            prog.add(ca.fwd(self.acts[i - 1], ra))
-            norm(i, ra, sa, ACT_RELU, out=self.mid[k])
-            prog.add(cb.fwd(self.mid[k], rb))
-            norm(i, rb, sb, ACT_NONE, residual=self.acts[i - 1])
+            prog.add(ca.fwd(self.acts[i - 1], ra, stats_ws=net.in_ws(self.B, ra.C)))
+            norm(i, ra, sa, ACT_RELU, out=self.mid[k], conv=ca)
+            prog.add(cb.fwd(self.mid[k], rb, stats_ws=net.in_ws(self.B, rb.C)))
+            norm(i, rb, sb, ACT_NONE, residual=self.acts[i - 1], conv=cb)
         for j in range(2):
             i = 3 + nb + j
             if i > self.last:

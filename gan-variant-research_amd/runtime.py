@@ -89,6 +89,7 @@ class ConvCall:
     mask_x0: int = 0
     max_tapoff: int = 0
     w_frag: bool = False      # w is the fragment-major copy (range-patch kernel)
+    stats: Optional[torch.Tensor] = None   # InstanceNorm partials written by the epilogue (see HipOps.conv_stats_parts)
 
 
 @dataclass
@@ -204,7 +205,7 @@ class HipOps:
         if c.mask is not None:
             assert c.mask.C == c.out.C and c.mask.dtype == c.out.dtype
             d.mask, d.mask_Hp, d.mask_Wp, d.mask_y0, d.mask_x0 = c.mask.ptr(), c.mask.Hp, c.mask.Wp, c.mask_y0, c.mask_x0
-        d.stats = None
+        d.stats = c.stats.data_ptr() if c.stats is not None else None
         d.max_tapoff = c.max_tapoff
         d.w_layout = 1 if c.w_frag else 0
         assert c.out.dtype == c.x.dtype
@@ -213,6 +214,13 @@ class HipOps:
     def conv_patch_ok(self, c: ConvCall) -> bool:
         """True if the range-patch kernel takes this call (then `c.w` must be the fragment-major weight copy)."""
         return bool(self.lib.gan_conv_patch_ok(C.byref(self._conv_desc(c))))
+
+    def conv_stats_parts(self, c: ConvCall) -> int:
+        """Pixel tiles per image for which this call can write InstanceNorm partials in its epilogue (0: it cannot)."""
+        return int(self.lib.gan_conv_stats_parts(C.byref(self._conv_desc(c))))
+
+    def in_stats_from_parts(self, parts, nparts, B, Cc, HW, eps, stats) -> Op:
+        return self._call("gan_in_stats_from_parts", self._p(parts), nparts, B, Cc, HW, C.c_float(eps), self._p(stats), self._s())
 
     def conv_igemm(self, c: ConvCall) -> Op:
         self._keep.append(c)

@@ -57,8 +57,9 @@ typedef struct gan_conv_desc {
   const void* mask;              /* optional LeakyReLU-derivative mask: result *= (mask>0 ? 1 : 0.2); element
                                     ((b*mask_Hp + ho*out_sy + mask_y0)*mask_Wp + wo*out_sx + mask_x0)*out_C + n */
   int32_t mask_Hp, mask_Wp, mask_y0, mask_x0;
-  float* stats;                  /* optional fp32 [B][out_C][2]: += per-(b,n) sum and sum of squares of the
-                                    pre-activation result (InstanceNorm statistics fused in the epilogue) */
+  float* stats;                  /* optional InstanceNorm partials fp32 [B][P][out_C][2], P = gan_conv_stats_parts(desc) > 0: per
+                                    (image, pixel tile, channel) sum and sum of squares of the result (bias included, before its
+                                    rounding to the output type), written with plain stores (deterministic); act must be none */
   int32_t max_tapoff;            /* largest value in tapoff[] (needed by the range-patch kernel's span check) */
   int32_t w_layout;              /* 0: w is [Nw][ntaps][Cin] (generic kernel); 1: fragment-major [Nw/16][ntaps*Cin/32][64][8]
                                     for the range-patch kernel (the descriptor must satisfy gan_conv_patch_ok) */
@@ -93,6 +94,8 @@ int gan_conv_igemm(const gan_conv_desc* d, void* stream);
 /* 1 if the descriptor qualifies for the range-patch kernel (bf16, Cin % 64 == 0, Nw % 128 == 0, one tile's pixel span fits
  * the LDS slab); pure host-side predicate used by the planner to choose the weight layout */
 int gan_conv_patch_ok(const gan_conv_desc* d);
+/* pixel tiles per image for which the descriptor's launch writes InstanceNorm partials to d->stats; 0: it cannot (then use gan_in_stats) */
+int gan_conv_stats_parts(const gan_conv_desc* d);
 int gan_conv_wgrad(const gan_wgrad_desc* d, void* stream);
 /* splits per image the range-patch weight-gradient kernel wants (0: the descriptor does not qualify: bf16, 9 taps, stride 1,
  * Cx % 64 == 0, N % 128 == 0, one 128-pixel stage's window span fits LDS); pure host-side predicate for the planner */
@@ -120,7 +123,9 @@ int gan_bias_grad(const gan_view* g, int N_real, float* grad, int accumulate, fl
  *      nn.ReflectionPad2d and the residual add (generator_resnet_attn.py:25,43,56,64,71,111,114-115,126-127,150-151,158;
  *      Basic_GAN/src/models.py:10-18,30-31,38-39,52-53,91-92,99-100).  stats = fp32 [B][C][2] (mean, rstd). */
 int gan_in_stats(const gan_view* x, float eps, float* stats, float* ws, void* stream);
-/* turns fused-epilogue sums (gan_conv_desc.stats: sum, sum of squares) into (mean, rstd) in place */
+/* (mean, rstd) from the per-tile partials a convolution epilogue wrote to gan_conv_desc.stats (parts = [B][nparts][C][2]) */
+int gan_in_stats_from_parts(const float* parts, int nparts, int B, int C, int HW, float eps, float* stats, void* stream);
+/* turns whole-image sums (sum, sum of squares) into (mean, rstd) in place */
 int gan_in_finalize(float* stats, int BC, int HW, float eps, void* stream);
 int gan_in_apply(const gan_view* x, const float* stats, int act, const gan_view* residual, const gan_view* y,
                  int halo_mode, void* stream);

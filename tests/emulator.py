@@ -82,6 +82,18 @@ class EmuOps:
         jump = max(0, c.x.Wp * c.in_sy - c.Wo * c.in_sx)
         return (rows - 1) * c.in_sx + wraps * jump + c.max_tapoff // c.Cin + 1 <= 448
 
+    def conv_stats_parts(self, c):
+        """Statement of gan_conv_stats_parts; the emulator reports one part per image."""
+        return 1 if (self.conv_patch_ok(c) and c.act == ACT_NONE and c.mask is None and (c.out_sy, c.out_sx) == (1, 1)) else 0
+
+    def in_stats_from_parts(self, parts, nparts, B, Cc, HW, eps, stats):
+        def op():
+            p = parts[:B * nparts * Cc * 2].view(B, nparts, Cc, 2).double().sum(1)
+            mean = p[..., 0] / HW
+            var = (p[..., 1] / HW - mean * mean).clamp_min(0)
+            stats[:B * Cc * 2].view(B, Cc, 2).copy_(torch.stack([mean, 1.0 / torch.sqrt(var + eps)], -1).float())
+        return op
+
     @staticmethod
     def _unfrag(wf, Nw, K):
         """fragment-major [Nw/16][K/32][fg 4][fr 16][8] -> row-major [Nw][K]"""
@@ -113,6 +125,9 @@ class EmuOps:
             v = acc[..., :c.Nst]
             if c.bias is not None:
                 v = v + c.bias[:c.Nst].float()
+            if getattr(c, "stats", None) is not None:   # fused InstanceNorm partials: one part per image here (any tiling sums to the same)
+                assert self.conv_stats_parts(c) == 1 and c.Nst == c.out.C
+                c.stats[:c.B * c.Nst * 2].view(c.B, 1, c.Nst, 2).copy_(torch.stack([v.sum((1, 2)), (v * v).sum((1, 2))], -1).unsqueeze(1))
             v = _act(v, c.act)
             oy = c.out_y0 + torch.arange(c.Ho) * c.out_sy
             ox = c.out_x0 + torch.arange(c.Wo) * c.out_sx

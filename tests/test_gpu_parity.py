@@ -271,3 +271,40 @@ def test_module_step_hip(monkeypatch):
     from tests.test_autograd_bridge import module_step_cases
     monkeypatch.setattr(L, "_PLANS", {})
     module_step_cases(DEV, 1e-3, 2e-3)
+
+
+@pytest.mark.parametrize("bm", ["256", "288"])
+@pytest.mark.parametrize("H", [16, 20])
+def test_conv_fused_instance_norm_statistics(bm, H, monkeypatch):
+    """Per-tile (sum, sum of squares) written by the range-patch epilogue + gan_in_stats_from_parts == InstanceNorm statistics of the
+    convolution result; both tile heights, a map with a partial last tile (H=20: 400 pixels)."""
+    from gan_variant_research_amd.convplan import ConvLayer
+    monkeypatch.setenv("GAN_PATCH_BM", bm)
+    B, Cc = 3, 256
+    tw = Twin(BF16, seed=11)
+    xc, xg = tw.view(B, H, H, Cc, 1)
+    yc, yg = tw.view(B, H, H, Cc, 0, rand=False)
+    w = torch.randn(Cc, Cc, 3, 3, generator=tw.gen) * 0.03
+    b = torch.randn(Cc, generator=tw.gen) * 0.5
+    stats, parts = [], []
+    for ctx, x, y in ((tw.c, xc, yc), (tw.g, xg, yg)):
+        dev = ctx.device
+        layer = ConvLayer(ctx, w.to(dev), b.to(dev), torch.zeros_like(w).to(dev), torch.zeros_like(b).to(dev), 3, 1, 1)
+        ws = ctx.f32(B * 96 * Cc * 2)
+        ops = layer.fwd(x, y, stats_ws=ws)
+        assert layer.stats_parts > 0
+        parts.append(layer.stats_parts)
+        st = ctx.f32(B * Cc * 2)
+        for o in layer.repack_ops() + ops + [ctx.ops.in_stats_from_parts(ws, layer.stats_parts, B, Cc, H * H, 1e-5, st)]:
+            o()
+        stats.append(st)
+    torch.cuda.synchronize()
+    assert parts[1] == -(-H * H // int(bm))
+    tw.check(2e-2, 2e-2)                       # the convolution result itself
+    sc, sg = stats[0].view(B, Cc, 2), stats[1].cpu().view(B, Cc, 2)
+    np.testing.assert_allclose(sg[..., 0].numpy(), sc[..., 0].numpy(), rtol=2e-3, atol=2e-3)   # mean
+    np.testing.assert_allclose(sg[..., 1].numpy(), sc[..., 1].numpy(), rtol=2e-3)              # rstd
+    # and they are the statistics of the (unrounded) convolution result
+    ref = torch.nn.functional.conv2d(xc.padded().float().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), b)   # the halo is part of the view
+    np.testing.assert_allclose(sg[..., 0].numpy(), ref.mean((2, 3)).numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(sg[..., 1].numpy(), (1.0 / torch.sqrt(ref.var((2, 3), unbiased=False) + 1e-5)).numpy(), rtol=2e-3)
