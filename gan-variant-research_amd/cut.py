@@ -413,7 +413,32 @@ class CutTrainer:
                 pr.add(ops.fill(conv.grad_b, 0.0))
         r1_body, r1_skip = pr, skip
 
-        # ---- G step (train_cutpp.py:266-308)
+        # ---- G step (train_cutpp.py:266-308).  Two programs: `prog_g_features` -- the PatchNCE target-feature forward G.encode(fake)
+        # and the PatchNCE losses -- does not touch the discriminator, so it runs while the discriminator's gradient all-reduce is
+        # in flight on the communication stream (train_step); `prog_g_compute` needs the updated discriminator.
+        pf = Program("G-features")
+        # The generator's gradient block is cleared once and every pass ACCUMULATES into it: the feature pass (p2) stops at the last
+        # PatchNCE layer, so "first pass writes, later passes add" would leave the layers behind it (upsample.3, output.1) adding
+        # into the previous step's values.
+        pf.add(ops.zero_(self.opt_G.flat_g))
+        hooks = {}
+        if self.nce_layers:
+            pf.add(self.p2.fwd_program(self.p1.img))
+            pf.add(ops.fill(self._slot("nce"), 0.0))
+            wl = lw["patchnce"] / len(self.nce_layers)
+            for li, ids in zip(self.nce_layers, self.nce_ids):
+                src, tgt = self.p1.acts[li], self.p2.acts[li]
+                P = ids.numel()
+                ws = ctx.f32(ops.patchnce_ws_floats(B, P, src.C))
+                pf.add(ops.patchnce_fwd(src, tgt, ids, P, src.C, cfg["patchnce"]["temperature"], wl, self._slot("nce"), ws))
+
+                def mk(tgt=tgt, ids=ids, P=P, ws=ws):
+                    def hook(gv: View):
+                        assert (gv.H, gv.W, gv.C) == (tgt.H, tgt.W, tgt.C)
+                        return [ops.patchnce_bwd(tgt, ids, P, tgt.C, cfg["patchnce"]["temperature"], wl, gv, ws)]
+                    return hook
+                hooks[li] = mk()
+        self.prog_g_features = pf
         pg = Program("G-step")
         dp = self.d_fake
         pg.add(self._aug_fwd(self.p1.img, dp.x, self.prm["fake_g"]))
@@ -426,28 +451,8 @@ class CutTrainer:
             pg.add(ops.diffaug_bwd(dp.g_input, 3, self.prm["fake_g"], g_adv_img, ctx.scratch("aug_ws", B + 16)))
         else:
             g_adv_img = dp.g_input
-        # The generator's gradient block is cleared once and every pass ACCUMULATES into it: the feature pass (p2) stops at the last
-        # PatchNCE layer, so "first pass writes, later passes add" would leave the layers behind it (upsample.3, output.1) adding
-        # into the previous step's values.
-        pg.add(ops.zero_(self.opt_G.flat_g))
         g_img, g_fold, g_img2 = g_adv_img, False, None
         if self.nce_layers:
-            pg.add(self.p2.fwd_program(self.p1.img))
-            pg.add(ops.fill(self._slot("nce"), 0.0))
-            wl = lw["patchnce"] / len(self.nce_layers)
-            hooks = {}
-            for li, ids in zip(self.nce_layers, self.nce_ids):
-                src, tgt = self.p1.acts[li], self.p2.acts[li]
-                P = ids.numel()
-                ws = ctx.f32(ops.patchnce_ws_floats(B, P, src.C))
-                pg.add(ops.patchnce_fwd(src, tgt, ids, P, src.C, cfg["patchnce"]["temperature"], wl, self._slot("nce"), ws))
-
-                def mk(tgt=tgt, ids=ids, P=P, ws=ws):
-                    def hook(gv: View):
-                        assert (gv.H, gv.W, gv.C) == (tgt.H, tgt.W, tgt.C)
-                        return [ops.patchnce_bwd(tgt, ids, P, tgt.C, cfg["patchnce"]["temperature"], wl, gv, ws)]
-                    return hook
-                hooks[li] = mk()
             pg.add(self.p2.bwd_program(hooks=hooks, accumulate=True, need_input_grad=True))
             g_img, g_fold, g_img2 = self.p2.g_input, True, g_adv_img
         pg.add(self.p1.bwd_program(g_img, g_fold, g_img2, accumulate=True))
@@ -498,10 +503,34 @@ class CutTrainer:
         for dst, ids in zip(self.nce_ids, rnd["nce_ids"]):
             dst.copy_(ids.to(torch.int32))
 
+    def _allreduce_start(self, opt: FusedAdam):
+        """Launches the gradient all-reduce (sum; the optimiser divides by world_size) of one flat block on the communication
+        stream -- RCCL over xGMI -- and returns a handle; kernels queued on the compute stream meanwhile overlap with it."""
+        if not (self.world_size > 1 or getattr(self, "force_allreduce", False)):
+            return None
+        import torch.distributed as dist
+        if self.device.type != "cuda":
+            return dist.all_reduce(opt.flat_g, group=self.pg, async_op=True), None
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        self._comm_stream.wait_stream(cur)                       # the gradients are complete
+        with torch.cuda.stream(self._comm_stream):
+            work = dist.all_reduce(opt.flat_g, group=self.pg, async_op=True)
+        return work, cur
+
+    def _allreduce_finish(self, handle):
+        if handle is None:
+            return
+        work, cur = handle
+        work.wait()                                              # on CUDA: the compute stream waits for the collective, the host does not
+        if cur is not None:
+            cur.wait_stream(self._comm_stream)
+
+    _comm_stream = None
+
     def _allreduce(self, opt: FusedAdam):
-        if self.world_size > 1 or getattr(self, "force_allreduce", False):
-            import torch.distributed as dist
-            dist.all_reduce(opt.flat_g, group=self.pg)   # RCCL over xGMI; sum, the optimiser divides by world_size
+        self._allreduce_finish(self._allreduce_start(opt))
 
     # ------------------------------------------------------------------ the step
     def train_step(self, step: int, photos: torch.Tensor, monets: torch.Tensor, rnd: Optional[dict] = None, sync: bool = True):
@@ -521,7 +550,9 @@ class CutTrainer:
         self.losses[LOSS_SLOTS["idw"]] = idw
         self.prog_gfwd.run()
         self.prog_d_compute.run()
-        self._allreduce(self.opt_D)
+        h = self._allreduce_start(self.opt_D)      # overlaps with the PatchNCE feature forward, which does not need D
+        self.prog_g_features.run()
+        self._allreduce_finish(h)
         self.prog_d_update.run()
         if do_r1:
             self.prog_r1_compute.run()
