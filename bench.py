@@ -55,7 +55,7 @@ def dominant_kernel_roofline(trainer, iters=10):
     reported beside it as `res_fwd_*`."""
     bf16 = trainer.amp.enabled
     progs = [trainer.prog_gfwd, trainer.prog_d_compute, trainer.prog_d_update, trainer.prog_g_features, trainer.prog_g_compute, trainer.prog_g_identity, trainer.prog_g_update]
-    calls = [o for p in progs for o in p.ops if getattr(o, "conv", None) is not None and (o.conv.w_frag or not bf16)]
+    calls = [o for p in progs if p is not None for o in p.ops if getattr(o, "conv", None) is not None and (o.conv.w_frag or not bf16)]
     flops = sum(2.0 * o.conv.B * o.conv.Ho * o.conv.Wo * o.conv.Nst * o.conv.Cin * o.conv.ntaps for o in calls)
 
     def timed(ops, n):
@@ -74,14 +74,14 @@ def dominant_kernel_roofline(trainer, iters=10):
     conv = trainer.G.c_blk[0][0]
     x, y = trainer.p1.acts[2], trainer.p1.raw[3][0]
     res_ms = timed(conv.fwd(x, y), 20)
-    res_flops = 2.0 * x.B * y.H * y.W * conv.cout * conv.cin * 9
+    res_flops = 2.0 * x.B * y.H * y.W * conv.cout * conv.cin * 9   # x.B = 2 x batch while the identity pass rides in the generator pass
     peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
     ach = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": pmc_traffic("conv_patch_kernel") if bf16 else None,
             "kernel": "conv_patch_kernel" if bf16 else "conv_igemm_kernel<float,...>",
             "launches_per_step": len(calls), "flop_per_step": flops, "ms_per_launch": round(ms / max(len(calls), 1), 5),
-            "share_of_step_conv_flop": round(flops / (GFLOP_PER_IMAGE * 1e9 * x.B), 3),
+            "share_of_step_conv_flop": round(flops / (GFLOP_PER_IMAGE * 1e9 * trainer.B), 3),
             "res_fwd_tflops": round(res_flops / (res_ms * 1e-3) / 1e12, 2), "res_fwd_ms": round(res_ms, 4)}
 
 

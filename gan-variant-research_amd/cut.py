@@ -18,7 +18,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ._lib import ACT_NONE, BF16, F32, HALO_ZERO
+from ._lib import ACT_NONE, BF16, F32, HALO_NONE, HALO_ZERO
 from .nets import DiscriminatorNet, GeneratorNet
 from .runtime import ADAM_CHUNK, Ctx, HipOps, Program, View, cpad
 
@@ -345,23 +345,24 @@ class CutTrainer:
                                                                           ndf=discriminator.ndf, n_layers=discriminator.n_layers)
         self.nce_layers = feature_layers_present(config["patchnce"]["nce_layers"], nb) if lw["patchnce"] > 0 else []
         self.P = config["patchnce"]["num_patches"]
-        self.p1 = self.G.new_pass(B, S, S)
+        # Identity warm-up (identity weight > 0): G(photos) and G(monets) are two full passes through the same weights, and
+        # InstanceNorm is per sample -> they run as ONE pass over 2B images (half the launches, one split-K reduction per layer);
+        # after the warm-up the generator pass holds the photos only.  `merge_identity_pass: false` keeps three separate passes.
+        self.merge_identity = bool(config.get("merge_identity_pass", True))
         self.p2 = self.G.new_pass(B, S, S, last_layer=max(self.nce_layers)) if self.nce_layers else None
-        self.p3 = self.G.new_pass(B, S, S)
         self.d_real, self.d_fake = self.D.new_pass(B, S, S), self.D.new_pass(B, S, S)
         self.d_r1 = self.D32.new_pass(B, S, S)
 
         f32 = self.ctx.f32
-        self.photos = torch.zeros(B, 3, S, S, dtype=torch.float32, device=self.device)
-        self.monets = torch.zeros_like(self.photos)
+        self.both = torch.zeros(2 * B, 3, S, S, dtype=torch.float32, device=self.device)   # photos | monets, one staging tensor
+        self.photos, self.monets = self.both[:B], self.both[B:]
         self.fake_out = torch.zeros_like(self.photos)
         self.losses = f32(16)
         self.prm = {k: f32(B * 12) for k in ("real", "fake_d", "fake_g")}
-        self.nce_hw = [self.p1.acts[i].H * self.p1.acts[i].W for i in self.nce_layers]
+        self.nce_hw = [(S >> (0 if i == 0 else 1 if i == 1 else 2 if i < 3 + nb else 1 if i == 3 + nb else 0)) ** 2 for i in self.nce_layers]
         self.nce_ids = [torch.zeros(min(self.P, hw), dtype=torch.int32, device=self.device) for hw in self.nce_hw]
-        self._build_programs()
-        self.G.repack_program().run()
-        self.D.repack_program().run()
+        self._modes = {}
+        self._use_mode(self.merge_identity and identity_weight_at(0, config) > 0)
 
     # ------------------------------------------------------------------ program construction
     def _slot(self, name) -> torch.Tensor:
@@ -374,44 +375,48 @@ class CutTrainer:
             return [ops.view_copy(src, dst, HALO_ZERO)]
         return [ops.diffaug_fwd(src, 3, prm, dst, self.ctx.scratch("aug_ws", self.B + 16))]
 
-    def _build_programs(self):
+    def _use_mode(self, merged: bool):
+        """Makes the step programs of one mode current (building them on first use).  merged: the identity pass rides in the
+        generator pass (2B images); otherwise G(photos) and G(monets) are separate passes and the latter is optional."""
+        if merged not in self._modes:
+            self._modes[merged] = self._build_mode(merged)
+            self._build_updates()            # repack programs must see every operand copy planned so far
+            self.G.repack_program().run()
+            self.D.repack_program().run()
+        m = self._modes[merged]
+        self.mode_merged = merged
+        for k, val in m.items():
+            setattr(self, k, val)
+
+    def _build_mode(self, merged: bool) -> dict:
         cfg, ops, ctx, B, S = self.config, self.ops, self.ctx, self.B, self.S
         lw = cfg["loss_weights"]
-        gs = 1.0 / self.world_size
-        # ---- shared generator forward
-        self.prog_gfwd = self.p1.fwd_program(self.photos)
+        if merged:
+            p1 = self.G.new_pass(2 * B, S, S)
+            p3 = None
+            fake = p1.img.batch(0, B)
+            prog_gfwd = p1.fwd_program(self.both)
+        else:
+            p1, p3 = self.G.new_pass(B, S, S), self.G.new_pass(B, S, S)
+            fake = p1.img
+            prog_gfwd = p1.fwd_program(self.photos)
+
+        def src_feat(li):
+            return p1.acts[li].batch(0, B) if merged else p1.acts[li]
         # photos as a plain C=8 image view (DiffAugment / R1 input)
-        self.photos_v = ctx.view(B, S, S, 8, 0)
-        self.prog_gfwd.add(ops.nchw_to_view(self.photos, 3, self.photos_v, HALO_ZERO))
+        photos_v = ctx.view(B, S, S, 8, 0)
+        prog_gfwd.add(ops.nchw_to_view(self.photos, 3, photos_v, HALO_ZERO))
 
         # ---- D step (train_cutpp.py:231-254)
         pd = Program("D-step")
-        pd.add(self._aug_fwd(self.photos_v, self.d_real.x, self.prm["real"]))
-        pd.add(self._aug_fwd(self.p1.img, self.d_fake.x, self.prm["fake_d"]))
+        pd.add(self._aug_fwd(photos_v, self.d_real.x, self.prm["real"]))
+        pd.add(self._aug_fwd(fake, self.d_fake.x, self.prm["fake_d"]))
         pd.add(self.d_real.fwd_program())
         pd.add(self.d_fake.fwd_program())
         for i, (dp, mode, slot) in enumerate(((self.d_real, 0, "d_real"), (self.d_fake, 1, "d_fake"))):
             gl = dp.grad_logits_view()
             pd.add(ops.patch_loss(dp.logits, mode, 0.0, 0.5, self._slot(slot), gl))
             pd.add(dp.bwd_program(gl, wgrad=True, accumulate=(i == 1)))
-        self.prog_d_compute = pd
-
-        # ---- lazy R1 (train_cutpp.py:165-203, 257-263), always fp32 like the reference
-        pr = Program("R1-body")
-        rp, c32, dnet = self.d_r1, self.ctx32, self.D32
-        pr.add(ops.nchw_to_view(self.photos, 3, rp.x, HALO_ZERO))
-        pr.add(rp.fwd_program())
-        scale = cfg["r1"]["gamma"] * cfg["r1"]["every"]
-        pr.add(rp.r1_program(scale, self._slot("r1"), self._slot("scratch")))
-        skip = []
-        for li, conv in enumerate(dnet.convs):   # biases: zero grad except the last one, whose grad is None (skipped)
-            if conv.grad_b is None:
-                continue
-            if li == dnet.nconv - 1:
-                skip.append([k for k, v in self.opt_D.grads.items() if v is conv.grad_b][0])
-            else:
-                pr.add(ops.fill(conv.grad_b, 0.0))
-        r1_body, r1_skip = pr, skip
 
         # ---- G step (train_cutpp.py:266-308).  Two programs: `prog_g_features` -- the PatchNCE target-feature forward G.encode(fake)
         # and the PatchNCE losses -- does not touch the discriminator, so it runs while the discriminator's gradient all-reduce is
@@ -423,11 +428,11 @@ class CutTrainer:
         pf.add(ops.zero_(self.opt_G.flat_g))
         hooks = {}
         if self.nce_layers:
-            pf.add(self.p2.fwd_program(self.p1.img))
+            pf.add(self.p2.fwd_program(fake))
             pf.add(ops.fill(self._slot("nce"), 0.0))
             wl = lw["patchnce"] / len(self.nce_layers)
             for li, ids in zip(self.nce_layers, self.nce_ids):
-                src, tgt = self.p1.acts[li], self.p2.acts[li]
+                src, tgt = src_feat(li), self.p2.acts[li]
                 P = ids.numel()
                 ws = ctx.f32(ops.patchnce_ws_floats(B, P, src.C))
                 pf.add(ops.patchnce_fwd(src, tgt, ids, P, src.C, cfg["patchnce"]["temperature"], wl, self._slot("nce"), ws))
@@ -438,10 +443,9 @@ class CutTrainer:
                         return [ops.patchnce_bwd(tgt, ids, P, tgt.C, cfg["patchnce"]["temperature"], wl, gv, ws)]
                     return hook
                 hooks[li] = mk()
-        self.prog_g_features = pf
         pg = Program("G-step")
         dp = self.d_fake
-        pg.add(self._aug_fwd(self.p1.img, dp.x, self.prm["fake_g"]))
+        pg.add(self._aug_fwd(fake, dp.x, self.prm["fake_g"]))
         pg.add(dp.fwd_program())
         gl = dp.grad_logits_view()
         pg.add(ops.patch_loss(dp.logits, 2, 0.0, lw["adv"], self._slot("g_adv"), gl))
@@ -455,31 +459,65 @@ class CutTrainer:
         if self.nce_layers:
             pg.add(self.p2.bwd_program(hooks=hooks, accumulate=True, need_input_grad=True))
             g_img, g_fold, g_img2 = self.p2.g_input, True, g_adv_img
-        pg.add(self.p1.bwd_program(g_img, g_fold, g_img2, accumulate=True))
-        self.prog_g_compute = pg
-        # identity (identity_l1.py:6-22): third pass, gradient scaled by the device-resident identity weight
-        pi = Program("G-identity")
-        pi.add(self.p3.fwd_program(self.monets))
-        g_idt = ctx.view(B, S, S, 8, 0)
-        pi.add(ops.l1_loss(self.p3.img, 3, self.monets, 1.0, self._slot("idw"), self._slot("identity"), g_idt, ctx.scratch("l1_ws", 1024)))
-        pi.add(self.p3.bwd_program(g_idt, accumulate=True))
-        self.prog_g_identity = pi
-        # ---- optimiser updates and operand-copy refresh: built LAST, when every conv call (hence every weight copy) is planned
+        pi = None
+        if merged:
+            # gradient wrt the 2B output images: [adversarial (+ folded PatchNCE input gradient) | identity L1 x identity weight]
+            g13 = ctx.view(2 * B, S, S, 8, 0)
+            if g_fold:
+                pg.add(ops.fold_add(g_img2, g_img, True, g13.batch(0, B)))
+            else:
+                pg.add(ops.view_copy(g_img, g13.batch(0, B), HALO_NONE))
+            pg.add(ops.l1_loss(p1.img.batch(B, B), 3, self.monets, 1.0, self._slot("idw"), self._slot("identity"), g13.batch(B, B),
+                               ctx.scratch("l1_ws", 1024)))
+            pg.add(p1.bwd_program(g13, accumulate=True))
+        else:
+            pg.add(p1.bwd_program(g_img, g_fold, g_img2, accumulate=True))
+            # identity (identity_l1.py:6-22): third pass, gradient scaled by the device-resident identity weight
+            pi = Program("G-identity")
+            pi.add(p3.fwd_program(self.monets))
+            g_idt = ctx.view(B, S, S, 8, 0)
+            pi.add(ops.l1_loss(p3.img, 3, self.monets, 1.0, self._slot("idw"), self._slot("identity"), g_idt, ctx.scratch("l1_ws", 1024)))
+            pi.add(p3.bwd_program(g_idt, accumulate=True))
+        pfo = Program("fake-out")
+        pfo.add(ops.view_to_nchw(fake, 3, self.fake_out))
+        return {"p1": p1, "p3": p3, "photos_v": photos_v, "prog_gfwd": prog_gfwd, "prog_d_compute": pd, "prog_g_features": pf, "prog_g_compute": pg,
+                "prog_g_identity": pi, "prog_fake_out": pfo}
+
+    def _build_updates(self):
+        """R1 and the optimiser updates with their operand-copy refresh: built after every mode planned so far, because a
+        repack program refreshes exactly the weight copies that exist when it is built."""
+        cfg, ops = self.config, self.ops
+        gs = 1.0 / self.world_size
+        if getattr(self, "_r1_body", None) is None:
+            # ---- lazy R1 (train_cutpp.py:165-203, 257-263), always fp32 like the reference
+            pr = Program("R1-body")
+            rp, dnet = self.d_r1, self.D32
+            pr.add(ops.nchw_to_view(self.photos, 3, rp.x, HALO_ZERO))
+            pr.add(rp.fwd_program())
+            scale = cfg["r1"]["gamma"] * cfg["r1"]["every"]
+            pr.add(rp.r1_program(scale, self._slot("r1"), self._slot("scratch")))
+            skip = []
+            for li, conv in enumerate(dnet.convs):   # biases: zero grad except the last one, whose grad is None (skipped)
+                if conv.grad_b is None:
+                    continue
+                if li == dnet.nconv - 1:
+                    skip.append([k for k, v in self.opt_D.grads.items() if v is conv.grad_b][0])
+                else:
+                    pr.add(ops.fill(conv.grad_b, 0.0))
+            self._r1_body, self._r1_skip = pr, skip
         self.prog_d_update = Program("D-update")
         self.prog_d_update.add(self.opt_D.step_op(cfg.get("grad_clip_d", 10.0), gs))
         self.prog_d_update.add(self.D.repack_program())
         self.prog_r1_compute = Program("R1")
         if self.D32 is not self.D:
             self.prog_r1_compute.add(self.D32.repack_program())   # fp32 operand copies are only needed on R1 steps
-        self.prog_r1_compute.add(r1_body)
+        self.prog_r1_compute.add(self._r1_body)
         self.prog_r1_update = Program("R1-update")
-        self.prog_r1_update.add(self.opt_D.step_op(cfg.get("grad_clip_d", 10.0), gs, skip=r1_skip))
+        self.prog_r1_update.add(self.opt_D.step_op(cfg.get("grad_clip_d", 10.0), gs, skip=self._r1_skip))
         self.prog_r1_update.add(self.D.repack_program())
         self.prog_g_update = Program("G-update")
         self.prog_g_update.add(self.opt_G.step_op(cfg.get("grad_clip_g", 10.0), gs))
         self.prog_g_update.add(self.G.repack_program())
-        self.prog_fake_out = Program("fake-out")
-        self.prog_fake_out.add(ops.view_to_nchw(self.p1.img, 3, self.fake_out))
 
     # ------------------------------------------------------------------ per-step randomness
     def sample_randomness(self, generator: Optional[torch.Generator] = None, nce_generator: Optional[torch.Generator] = None) -> dict:
@@ -545,6 +583,9 @@ class CutTrainer:
         self._load_randomness(rnd)
         self.photos.copy_(photos, non_blocking=True)
         self.monets.copy_(monets, non_blocking=True)
+        merged = self.merge_identity and idw > 0
+        if merged != self.mode_merged:
+            self._use_mode(merged)
         do_r1 = cfg["r1"]["gamma"] > 0 and step % cfg["r1"]["every"] == 0
         self.losses.zero_()
         self.losses[LOSS_SLOTS["idw"]] = idw
@@ -559,7 +600,7 @@ class CutTrainer:
             self._allreduce(self.opt_D)
             self.prog_r1_update.run()
         self.prog_g_compute.run()
-        if idw > 0:
+        if idw > 0 and self.prog_g_identity is not None:
             self.prog_g_identity.run()
         self._allreduce(self.opt_G)
         self.prog_g_update.run()

@@ -59,6 +59,11 @@ class View:
     def padded(self) -> torch.Tensor:
         return self.t.view(self.B, self.Hp, self.Wp, self.C)
 
+    def batch(self, b0: int, n: int) -> "View":
+        """Images b0 .. b0+n-1 as a view of the same storage."""
+        assert 0 <= b0 and b0 + n <= self.B
+        return View(self.t.view(self.B, -1)[b0:b0 + n].reshape(-1), n, self.H, self.W, self.C, self.halo, self.dtype)
+
 
 @dataclass
 class ConvCall:

@@ -1,5 +1,6 @@
 """Host logic on CPU: the engine (tap tables, halos, sub-pixel phases, program order, optimiser tables) driven through
 the emulator (tests/emulator.py) must reproduce the oracle.  No GPU, no HIP kernel launches."""
+import numpy as np
 import pytest
 import torch
 
@@ -117,3 +118,35 @@ def test_lagged_loss_readback_delivers_every_step():
     got = [b.train_step(s, photos, monets, rnds[s], sync="lag") for s in range(3)]
     assert got[0] is None and got[1] == want[0] and got[2] == want[1]
     assert b.flush_losses() == want[2] and b.flush_losses() is None
+
+
+def test_merged_identity_pass_equals_separate_passes_and_mode_switch():
+    """G(photos) and G(monets) as one 2B pass (identity warm-up) == three separate passes; when the identity weight reaches zero the
+    trainer switches to the photos-only programs (train_cutpp.py:224-228, 293-295)."""
+    B, S = 2, 32
+    g = torch.Generator().manual_seed(5)
+    photos, monets = torch.rand(B, 3, S, S, generator=g) * 2 - 1, torch.rand(B, 3, S, S, generator=g) * 2 - 1
+
+    def make(merge):
+        cfg = cases.small_config()
+        cfg["diffaugment"]["enable"] = True
+        cfg["warmup_steps"] = 2                      # identity weight: 0.1 at step 0, 0.05 at step 1, 0 from step 2 on
+        cfg["merge_identity_pass"] = merge
+        C.set_seed(42)
+        gen, disc = C.build_models(cfg, "cpu")
+        return C.CutTrainer(gen, disc, cfg, B, S, device="cpu", amp=False, ops=EmuOps())
+    a, b = make(True), make(False)
+    assert a.mode_merged and not b.mode_merged and a.p1.B == 2 * B and b.p1.B == B
+    for step in range(4):
+        torch.manual_seed(100 + step)
+        rnd = a.sample_randomness()
+        la, lb = a.train_step(step, photos, monets, rnd), b.train_step(step, photos, monets, rnd)
+        assert a.mode_merged == (step < 2)
+        assert la["identity_weight"] == lb["identity_weight"] and (la["identity"] == 0.0) == (step >= 2)
+        for k in la:
+            # from step 1 on, parameters whose gradient is rounding noise have moved by +-lr differently (SURVEY §7.2): same
+            # tolerances as the oracle comparison of tests/cases.py
+            np.testing.assert_allclose(la[k], lb[k], rtol=2e-5 if step == 0 else 2e-3, atol=1e-3 if (k == "g_adv" and step) else 2e-5,
+                                       err_msg=f"step {step} {k}")
+    worst = max(float((a.opt_G.params[k] - v).abs().max()) for k, v in b.opt_G.params.items())
+    assert worst < 8.5e-4, worst     # four sign-like Adam steps of lr 2e-4 on weights whose gradient is rounding noise

@@ -32,7 +32,7 @@ torch.cuda.synchronize()
 rows = collections.OrderedDict()
 tot = 0.0
 for pname in ["prog_gfwd", "prog_d_compute", "prog_d_update", "prog_g_features", "prog_g_compute", "prog_g_identity", "prog_g_update"]:
-    for op in getattr(tr, pname).ops:
+    for op in (getattr(tr, pname).ops if getattr(tr, pname) is not None else []):
         for _ in range(2):
             op()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
