@@ -350,7 +350,7 @@ class CutTrainer:
         # after the warm-up the generator pass holds the photos only.  `merge_identity_pass: false` keeps three separate passes.
         self.merge_identity = bool(config.get("merge_identity_pass", True))
         self.p2 = self.G.new_pass(B, S, S, last_layer=max(self.nce_layers)) if self.nce_layers else None
-        self.d_real, self.d_fake = self.D.new_pass(B, S, S), self.D.new_pass(B, S, S)
+        self.d_rf, self.d_fake = self.D.new_pass(2 * B, S, S), self.D.new_pass(B, S, S)   # D-step pass (real | fake), G-step pass
         self.d_r1 = self.D32.new_pass(B, S, S)
 
         f32 = self.ctx.f32
@@ -407,16 +407,17 @@ class CutTrainer:
         photos_v = ctx.view(B, S, S, 8, 0)
         prog_gfwd.add(ops.nchw_to_view(self.photos, 3, photos_v, HALO_ZERO))
 
-        # ---- D step (train_cutpp.py:231-254)
+        # ---- D step (train_cutpp.py:231-254): D(aug(photos)) and D(aug(fake.detach())) as ONE pass over 2B images (the
+        # discriminator has no cross-sample statistics); the two hinge terms read / write their halves of the logits
         pd = Program("D-step")
-        pd.add(self._aug_fwd(photos_v, self.d_real.x, self.prm["real"]))
-        pd.add(self._aug_fwd(fake, self.d_fake.x, self.prm["fake_d"]))
-        pd.add(self.d_real.fwd_program())
-        pd.add(self.d_fake.fwd_program())
-        for i, (dp, mode, slot) in enumerate(((self.d_real, 0, "d_real"), (self.d_fake, 1, "d_fake"))):
-            gl = dp.grad_logits_view()
-            pd.add(ops.patch_loss(dp.logits, mode, 0.0, 0.5, self._slot(slot), gl))
-            pd.add(dp.bwd_program(gl, wgrad=True, accumulate=(i == 1)))
+        drf = self.d_rf
+        pd.add(self._aug_fwd(photos_v, drf.x.batch(0, B), self.prm["real"]))
+        pd.add(self._aug_fwd(fake, drf.x.batch(B, B), self.prm["fake_d"]))
+        pd.add(drf.fwd_program())
+        gl = drf.grad_logits_view()
+        pd.add(ops.patch_loss(drf.logits.batch(0, B), 0, 0.0, 0.5, self._slot("d_real"), gl.batch(0, B)))
+        pd.add(ops.patch_loss(drf.logits.batch(B, B), 1, 0.0, 0.5, self._slot("d_fake"), gl.batch(B, B)))
+        pd.add(drf.bwd_program(gl, wgrad=True, accumulate=False))
 
         # ---- G step (train_cutpp.py:266-308).  Two programs: `prog_g_features` -- the PatchNCE target-feature forward G.encode(fake)
         # and the PatchNCE losses -- does not touch the discriminator, so it runs while the discriminator's gradient all-reduce is

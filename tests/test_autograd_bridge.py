@@ -325,7 +325,7 @@ def test_fused_trainer_matches_module_step_over_three_steps(monkeypatch):
         for k in a:
             np.testing.assert_allclose(a[k], b[k], rtol=2e-3, atol=1e-3 if k == "g_adv" else 2e-4, err_msg=f"step {step} {k}")
     worst = max(float((tr.opt_G.params[k] - v.data).abs().max()) for k, v in gen2.named_parameters() if not k.endswith(".bias"))
-    assert worst < 6.5e-4, worst    # three sign-like Adam steps of lr 2e-4 (a weight whose gradient is rounding noise can move +-lr per step)
+    assert worst < 1.3e-3, worst    # three sign-like Adam steps of lr 2e-4: a weight whose gradient is rounding noise can move +lr in one run and -lr in the other
 
 
 def test_inference_path_on_emulator(monkeypatch, tmp_path):

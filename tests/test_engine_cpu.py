@@ -149,4 +149,4 @@ def test_merged_identity_pass_equals_separate_passes_and_mode_switch():
             np.testing.assert_allclose(la[k], lb[k], rtol=2e-5 if step == 0 else 2e-3, atol=1e-3 if (k == "g_adv" and step) else 2e-5,
                                        err_msg=f"step {step} {k}")
     worst = max(float((a.opt_G.params[k] - v).abs().max()) for k, v in b.opt_G.params.items())
-    assert worst < 8.5e-4, worst     # four sign-like Adam steps of lr 2e-4 on weights whose gradient is rounding noise
+    assert worst < 1.7e-3, worst     # four sign-like Adam steps of lr 2e-4: +lr in one run, -lr in the other, on weights whose gradient is rounding noise
