@@ -223,9 +223,11 @@ class ConvLayer:
             ns -= 1
         return ns
 
-    def wgrad(self, x: View, dy: View, accumulate: bool, bias_too: bool = True):
-        """grad_w (+)= dL/dW from the layer input `x` and the output gradient `dy`."""
-        ctx, ops, k, p = self.ctx, self.ctx.ops, self.k, self.p
+    def wgrad(self, x: View, dy: View, accumulate: bool, bias_too: bool = True, ops=None):
+        """grad_w (+)= dL/dW from the layer input `x` and the output gradient `dy`.  ops: op layer to build the launches on
+        (default: the context's; the backward programs pass the second-stream layer)."""
+        ctx, k, p = self.ctx, self.k, self.p
+        ops = ctx.ops if ops is None else ops
         epc = 4 if ctx.dtype == F32 else 8
         if not self.transposed:
             g, xo, stride = dy, x, self.s

@@ -188,6 +188,27 @@ class GPass:
             if i in hooks:
                 prog.add(hooks[i](gv))
 
+        # Weight gradients go to a second HIP stream: they are MFMA-bound and nothing on the backward chain waits for them, so
+        # they overlap with the HBM-bound part of the chain (InstanceNorm backward, reflection folds: 63 % of its time hidden in a
+        # two-kernel probe).  An event after the producer of dy orders the side stream; before the main stream rewrites a dy buffer
+        # it waits for the side launches that read it; the program ends with a join.
+        side = ops.side()
+        readers = {}     # id(dy buffer) -> event recorded on the side stream after its last reader
+
+        def wgrad_side(conv, x, dy, bias_too):
+            ev = ops.new_event()
+            prog.add(ops.record(ev))
+            prog.add(side.wait(ev))
+            prog.add(conv.wgrad(x, dy, acc, bias_too=bias_too, ops=side))
+            done = ops.new_event()
+            prog.add(side.record(done))
+            readers[id(dy.t)] = done
+
+        def before_write(buf: View):
+            ev = readers.pop(id(buf.t), None)
+            if ev is not None:
+                prog.add(ops.wait(ev))
+
         def inbwd(raw, stats, act, gy, fold, dx, conv=None):
             """InstanceNorm backward; with `conv`, its bias gradient (column sums of dx) comes out of the same pass."""
             if conv is not None and conv.grad_b is not None:
@@ -202,7 +223,7 @@ class GPass:
             assert g_img is not None
             dyo = net.gbuf("dy_out", B, H, W, self.img.C, 6)
             prog.add(ops.act_bwd(self.img, ACT_TANH, g_img, g_img_fold, g_img2, dyo))
-            prog.add(net.c_out.wgrad(self.acts[-1], dyo, acc))
+            wgrad_side(net.c_out, self.acts[-1], dyo, True)
             g_cur = net.gbuf("g_h4", B, H, W, g, 3)
             prog.add(net.c_out.dgrad(dyo, g_cur, padded_domain=True))
             g_fold = True
@@ -217,7 +238,7 @@ class GPass:
             a_in = self.acts[i - 1]
             dy = net.gbuf(f"dy_up{j}", B, self.raw[i].H, self.raw[i].W, self.raw[i].C, 1)
             inbwd(self.raw[i], self.stats[i], ACT_RELU, g_cur, g_fold, dy, net.c_up[j])
-            prog.add(net.c_up[j].wgrad(a_in, dy, acc, bias_too=False))
+            wgrad_side(net.c_up[j], a_in, dy, False)
             g_cur = net.gbuf(f"g_act{a_in.H}x{a_in.C}", B, a_in.H, a_in.W, a_in.C, 0)
             prog.add(net.c_up[j].dgrad(dy, g_cur))
             g_fold = False
@@ -230,14 +251,16 @@ class GPass:
             ra, rb = self.raw[i]
             sa, sb = self.stats[i]
             c4, h4, w4 = ra.C, ra.H, ra.W
-            dyb = net.gbuf("dy_blk", B, h4, w4, c4, 2)
+            dyb = net.gbuf(f"dy_blk_b{k % 2}", B, h4, w4, c4, 2)   # two sets, alternating: the side stream reads them one block late
+            before_write(dyb)
             inbwd(rb, sb, ACT_NONE, g_cur, False, dyb, cb)
-            prog.add(cb.wgrad(self.mid[k], dyb, acc, bias_too=False))
+            wgrad_side(cb, self.mid[k], dyb, False)
             g_mid = net.gbuf("g_blk_p", B, h4, w4, c4, 1)
             prog.add(cb.dgrad(dyb, g_mid, padded_domain=True))
-            dya = net.gbuf("dy_blk", B, h4, w4, c4, 2)
+            dya = net.gbuf(f"dy_blk_a{k % 2}", B, h4, w4, c4, 2)
+            before_write(dya)
             inbwd(ra, sa, ACT_RELU, g_mid, True, dya, ca)
-            prog.add(ca.wgrad(self.acts[i - 1], dya, acc, bias_too=False))
+            wgrad_side(ca, self.acts[i - 1], dya, False)
             g_in_p = net.gbuf("g_blk_p", B, h4, w4, c4, 1)
             prog.add(ca.dgrad(dya, g_in_p, padded_domain=True))
             g_next = net.gbuf(f"g_res{k % 2}", B, h4, w4, c4, 0)
@@ -250,18 +273,21 @@ class GPass:
             a_in = self.acts[i - 1]
             dy = net.gbuf(f"dy_down{i}", B, self.raw[i].H, self.raw[i].W, self.raw[i].C, 1)
             inbwd(self.raw[i], self.stats[i], ACT_RELU, g_cur, False, dy, net.c_down[i - 1])
-            prog.add(net.c_down[i - 1].wgrad(a_in, dy, acc, bias_too=False))
+            wgrad_side(net.c_down[i - 1], a_in, dy, False)
             g_cur = net.gbuf(f"g_act{a_in.H}x{a_in.C}", B, a_in.H, a_in.W, a_in.C, 0)
             prog.add(net.c_down[i - 1].dgrad(dy, g_cur))
             i -= 1
         hook(0, g_cur)
         dy0 = net.gbuf("dy_init", B, H, W, g, 6 if need_input_grad else 0)
         inbwd(self.raw[0], self.stats[0], ACT_RELU, g_cur, False, dy0, net.c_init)
-        prog.add(net.c_init.wgrad(self.x0, dy0, acc, bias_too=False))
+        wgrad_side(net.c_init, self.x0, dy0, False)
         self.g_input = None
         if need_input_grad:
             self.g_input = net.gbuf("g_x0", B, H, W, self.x0.C, 3)   # padded domain: consumer folds
             prog.add(net.c_init.dgrad(dy0, self.g_input, padded_domain=True))
+        join = ops.new_event()       # everything after this program (next pass, all-reduce, optimiser) sees complete gradients
+        prog.add(side.record(join))
+        prog.add(ops.wait(join))
         return prog
 
 
@@ -358,12 +384,18 @@ class DPass:
         prog = Program("D.bwd")
         dy = g_logits
         self.g_input = None
+        side = ops.side() if (wgrad and keep is None) else None   # weight gradients on the second stream (see GPass.bwd_program)
         for li in range(net.nconv - 1, -1, -1):
             conv = net.convs[li]
             xin = self.acts[li - 1] if li > 0 else self.x
             if keep is not None:
                 keep.append(dy)
-            if wgrad:
+            if wgrad and side is not None:
+                ev = ops.new_event()
+                prog.add(ops.record(ev))
+                prog.add(side.wait(ev))
+                prog.add(conv.wgrad(xin, dy, accumulate, bias_too=bias_grads, ops=side))
+            elif wgrad:
                 prog.add(conv.wgrad(xin, dy, accumulate, bias_too=bias_grads))
             if li == 0:
                 if need_input_grad:
@@ -383,4 +415,8 @@ class DPass:
                 nxt = net.gbuf(tag, B, a.H, a.W, a.C, halo)
                 prog.add(ops.in_bwd(self.raw[li - 1], self.stats[li - 1], ACT_LRELU, g_a, False, None, nxt, net.in_ws(B, a.C)))
             dy = nxt
+        if side is not None:
+            join = ops.new_event()
+            prog.add(side.record(join))
+            prog.add(ops.wait(join))
         return prog

@@ -156,11 +156,35 @@ class HipOps:
 
     is_hip = True
 
-    def __init__(self, device: torch.device, stream: Optional[int] = None):
+    def __init__(self, device: torch.device, stream: Optional[int] = None, torch_stream=None):
         self.lib = _lib.load()
         self.device = device
         self.stream = stream  # None: torch's current stream at op-construction time
+        self.torch_stream = torch_stream   # the torch.cuda.Stream behind `stream` (needed for event record / wait)
         self._keep = []       # ctypes structs referenced by prebuilt calls
+        self._side = None
+
+    # ---- a second HIP stream: independent MFMA-bound launches (weight gradients) run there while the HBM-bound chain
+    #      (InstanceNorm backward, reflection folds) continues on the main stream; ordering by events recorded in the programs
+    def side(self) -> "HipOps":
+        if self._side is None:
+            ts = torch.cuda.Stream(device=self.device)
+            self._side = HipOps(self.device, stream=ts.cuda_stream, torch_stream=ts)
+        return self._side
+
+    def _ts(self):
+        return self.torch_stream if self.torch_stream is not None else torch.cuda.current_stream(self.device)
+
+    def new_event(self):
+        return torch.cuda.Event()
+
+    def record(self, ev) -> Op:
+        """ev marks everything queued so far on this op layer's stream."""
+        return lambda: ev.record(self._ts())
+
+    def wait(self, ev) -> Op:
+        """Launches queued after this on this op layer's stream start after `ev`."""
+        return lambda: self._ts().wait_event(ev)
 
     def _s(self):
         return C.c_void_p(self.stream if self.stream is not None else torch.cuda.current_stream(self.device).cuda_stream)

@@ -70,6 +70,19 @@ class EmuOps:
         self.device = torch.device("cpu")
 
     # ------------------------------------------------------------------ convolution family
+    # one "stream": the emulator executes ops in program order, so events are no-ops
+    def side(self):
+        return self
+
+    def new_event(self):
+        return None
+
+    def record(self, ev):
+        return lambda: None
+
+    def wait(self, ev):
+        return lambda: None
+
     def conv_patch_ok(self, c):
         """Statement of gan_conv_patch_ok (csrc/conv_patch.hip)."""
         if c.x.dtype != 1 or c.Cin < 64 or c.Cin % 64 or c.Nw % 128 or c.Nst % 8 or c.out.C % 8 or c.max_tapoff <= 0:
