@@ -167,6 +167,8 @@ class HipOps:
     # ---- a second HIP stream: independent MFMA-bound launches (weight gradients) run there while the HBM-bound chain
     #      (InstanceNorm backward, reflection folds) continues on the main stream; ordering by events recorded in the programs
     def side(self) -> "HipOps":
+        if os.environ.get("GAN_SINGLE_STREAM"):     # profiling aid: per-kernel durations without concurrent kernels stretching them
+            return self
         if self._side is None:
             ts = torch.cuda.Stream(device=self.device)
             self._side = HipOps(self.device, stream=ts.cuda_stream, torch_stream=ts)

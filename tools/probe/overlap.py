@@ -5,8 +5,11 @@ from gan_variant_research_amd import BF16, _lib
 from gan_variant_research_amd.convplan import ConvLayer
 from gan_variant_research_amd.runtime import Ctx, HipOps
 dev = torch.device("cuda:0")
-side = torch.cuda.Stream(device=dev)
-main = torch.cuda.current_stream(dev)
+print("priority range", torch.cuda.Stream.priority_range())
+HP = len(sys.argv) > 2 and sys.argv[2] == "hp"
+side = torch.cuda.Stream(device=dev, priority=0)
+main = torch.cuda.Stream(device=dev, priority=torch.cuda.Stream.priority_range()[1] if False else -1) if HP else torch.cuda.current_stream(dev)
+torch.cuda.set_stream(main)
 ops_a = HipOps(dev)
 ops_b = HipOps(dev, stream=side.cuda_stream)
 ca, cb = Ctx(ops_a, dev, BF16), Ctx(ops_b, dev, BF16)
