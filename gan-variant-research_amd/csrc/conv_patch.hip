@@ -12,12 +12,16 @@
 //    per wave) instead of one per tap-step, and ~6x less global->LDS traffic for 3x3 windows;
 //  * W operand: never touches LDS.  The weights are packed "fragment-major" ([n/16][k/32][lane][8 bf16], see
 //    gan_pack_weight layout 1), so a wave fetches each MFMA A-fragment with one fully coalesced 1 KB global_load_dwordx4
-//    straight from L2/L1 into operand registers, prefetched one whole tap (two MFMA k-steps) ahead in a second register set;
-//  * one persistent 512-thread block per CU (8 waves = 4(M) x 2(N), each 64x64 of v_mfma_f32_16x16x32_bf16) walks its
-//    256x128 tiles as one software pipeline: the next slab (or the next tile's first slab) is fetched to registers and
-//    written to the other LDS buffer while the current one computes, so tile boundaries cost no load latency;
+//    straight from L2/L1 into operand registers, prefetched one MFMA k-step ahead in a second register set;
+//  * one persistent 512-thread block per CU walks its tiles as one software pipeline: the next slab (or the next tile's
+//    first slab) is fetched to registers and written to the other LDS buffer while the current one computes, so tile
+//    boundaries cost no load latency.  Tile 256x128 (8 waves = 4(M) x 2(N), each 64x64 of v_mfma_f32_16x16x32_bf16) or
+//    288x128 (2 x 4 waves of 144x32), whichever needs fewer CU-rounds x rows; consecutive tiles of one pixel tile go to one XCD;
+//  * for exactly 9 taps the 256-row tile has a static schedule (NT = 9): unrolled tap loop, all fragment addresses of a tile
+//    precomputed, LDS buffer index folded into the ds_read immediate;
 //  * all global loads are plain VGPR loads (no LDS-DMA), so hipcc's counted s_waitcnt vmcnt(N) keeps the prefetch in flight;
-//  * the epilogue pairs lanes 16 apart (same pixel, adjacent channel quads) and writes 16-byte stores.
+//  * the epilogue pairs lanes 16 apart (same pixel, adjacent channel quads) and writes 16-byte stores; optionally it also
+//    emits the InstanceNorm statistics of its tile (gan_conv_desc.stats) with DPP row reductions.
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
