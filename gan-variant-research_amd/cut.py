@@ -319,7 +319,12 @@ class CutTrainer:
         self.amp = AMPContext(amp)
         self.ops = ops if ops is not None else HipOps(self.device)
         self.ctx = Ctx(self.ops, self.device, self.amp.dtype)
-        self.ctx32 = self.ctx if self.amp.dtype == F32 else Ctx(self.ops, self.device, F32)
+        # The discriminator lives on its own HIP stream: its step (forward / backward / R1 / Adam) and its forward-backward for the
+        # generator's adversarial gradient depend on the generator only through the fake image, so they run concurrently with the
+        # PatchNCE feature pass and its backward; two events per step order the streams (train_step).
+        self.opsD = self.ops.fork()
+        self.ctxD = Ctx(self.opsD, self.device, self.amp.dtype) if self.opsD is not self.ops else self.ctx
+        self.ctx32 = self.ctxD if self.amp.dtype == F32 else Ctx(self.opsD, self.device, F32)
         self.world_size, self.pg = world_size, process_group
         lw = config["loss_weights"]
         self.policy = config["diffaugment"].get("policy", ["color", "translation", "cutout"]) if config["diffaugment"].get("enable", False) else None
@@ -332,7 +337,7 @@ class CutTrainer:
         og, od = get_optimizer_config(config["optim"]["G"]), get_optimizer_config(config["optim"]["D"])
         self.opt_G = FusedAdam(self.ctx, list(gsd), [v.shape for v in gsd.values()], gsd, og["lr"], og["betas"], 1e-8, og["weight_decay"],
                                ema_decay=config["ema"]["decay"])
-        self.opt_D = FusedAdam(self.ctx, list(dsd), [v.shape for v in dsd.values()], dsd, od["lr"], od["betas"], 1e-8, od["weight_decay"])
+        self.opt_D = FusedAdam(self.ctxD, list(dsd), [v.shape for v in dsd.values()], dsd, od["lr"], od["betas"], 1e-8, od["weight_decay"])
         for mod, opt in ((generator, self.opt_G), (discriminator, self.opt_D)):   # modules now alias the trained block
             for k, p in mod.named_parameters():
                 p.data = opt.params[k]
@@ -340,8 +345,8 @@ class CutTrainer:
         B, S = self.B, self.S
         nb, ngf = generator.n_blocks, generator.ngf
         self.G = GeneratorNet(self.ctx, self.opt_G.params, self.opt_G.grads, "cut", nb, ngf, need_input_grad=True)
-        self.D = DiscriminatorNet(self.ctx, self.opt_D.params, self.opt_D.grads, "cut", ndf=discriminator.ndf, n_layers=discriminator.n_layers)
-        self.D32 = self.D if self.ctx32 is self.ctx else DiscriminatorNet(self.ctx32, self.opt_D.params, self.opt_D.grads, "cut",
+        self.D = DiscriminatorNet(self.ctxD, self.opt_D.params, self.opt_D.grads, "cut", ndf=discriminator.ndf, n_layers=discriminator.n_layers)
+        self.D32 = self.D if self.ctx32 is self.ctxD else DiscriminatorNet(self.ctx32, self.opt_D.params, self.opt_D.grads, "cut",
                                                                           ndf=discriminator.ndf, n_layers=discriminator.n_layers)
         self.nce_layers = feature_layers_present(config["patchnce"]["nce_layers"], nb) if lw["patchnce"] > 0 else []
         self.P = config["patchnce"]["num_patches"]
@@ -370,10 +375,10 @@ class CutTrainer:
         return self.losses[i:i + 1]
 
     def _aug_fwd(self, src: View, dst: View, prm) -> list:
-        ops = self.ops
+        ops = self.opsD                          # DiffAugment feeds the discriminator: its stream
         if self.aug is None:
             return [ops.view_copy(src, dst, HALO_ZERO)]
-        return [ops.diffaug_fwd(src, 3, prm, dst, self.ctx.scratch("aug_ws", self.B + 16))]
+        return [ops.diffaug_fwd(src, 3, prm, dst, self.ctxD.scratch("aug_ws", self.B + 16))]
 
     def _use_mode(self, merged: bool):
         """Makes the step programs of one mode current (building them on first use).  merged: the identity pass rides in the
@@ -381,12 +386,18 @@ class CutTrainer:
         if merged not in self._modes:
             self._modes[merged] = self._build_mode(merged)
             self._build_updates()            # repack programs must see every operand copy planned so far
+            self._device_sync()              # parameters may have been written on another stream (construction, checkpoint load)
             self.G.repack_program().run()
             self.D.repack_program().run()
+            self._device_sync()
         m = self._modes[merged]
         self.mode_merged = merged
         for k, val in m.items():
             setattr(self, k, val)
+
+    def _device_sync(self):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
 
     def _build_mode(self, merged: bool) -> dict:
         cfg, ops, ctx, B, S = self.config, self.ops, self.ctx, self.B, self.S
@@ -415,8 +426,8 @@ class CutTrainer:
         pd.add(self._aug_fwd(fake, drf.x.batch(B, B), self.prm["fake_d"]))
         pd.add(drf.fwd_program())
         gl = drf.grad_logits_view()
-        pd.add(ops.patch_loss(drf.logits.batch(0, B), 0, 0.0, 0.5, self._slot("d_real"), gl.batch(0, B)))
-        pd.add(ops.patch_loss(drf.logits.batch(B, B), 1, 0.0, 0.5, self._slot("d_fake"), gl.batch(B, B)))
+        pd.add(self.opsD.patch_loss(drf.logits.batch(0, B), 0, 0.0, 0.5, self._slot("d_real"), gl.batch(0, B)))
+        pd.add(self.opsD.patch_loss(drf.logits.batch(B, B), 1, 0.0, 0.5, self._slot("d_fake"), gl.batch(B, B)))
         pd.add(drf.bwd_program(gl, wgrad=True, accumulate=False))
 
         # ---- G step (train_cutpp.py:266-308).  Two programs: `prog_g_features` -- the PatchNCE target-feature forward G.encode(fake)
@@ -444,22 +455,27 @@ class CutTrainer:
                         return [ops.patchnce_bwd(tgt, ids, P, tgt.C, cfg["patchnce"]["temperature"], wl, gv, ws)]
                     return hook
                 hooks[li] = mk()
-        pg = Program("G-step")
+        # adversarial gradient of the generator's output: D(aug(fake)) forward and its input gradient, on the discriminator's stream
+        pa = Program("G-adversarial")
         dp = self.d_fake
-        pg.add(self._aug_fwd(fake, dp.x, self.prm["fake_g"]))
-        pg.add(dp.fwd_program())
+        pa.add(self._aug_fwd(fake, dp.x, self.prm["fake_g"]))
+        pa.add(dp.fwd_program())
         gl = dp.grad_logits_view()
-        pg.add(ops.patch_loss(dp.logits, 2, 0.0, lw["adv"], self._slot("g_adv"), gl))
-        pg.add(dp.bwd_program(gl, wgrad=False, need_input_grad=True))
+        pa.add(self.opsD.patch_loss(dp.logits, 2, 0.0, lw["adv"], self._slot("g_adv"), gl))
+        pa.add(dp.bwd_program(gl, wgrad=False, need_input_grad=True))
         if self.aug is not None:
-            g_adv_img = ctx.view(B, S, S, 8, 0)
-            pg.add(ops.diffaug_bwd(dp.g_input, 3, self.prm["fake_g"], g_adv_img, ctx.scratch("aug_ws", B + 16)))
+            g_adv_img = self.ctxD.view(B, S, S, 8, 0)
+            pa.add(self.opsD.diffaug_bwd(dp.g_input, 3, self.prm["fake_g"], g_adv_img, self.ctxD.scratch("aug_ws", B + 16)))
         else:
             g_adv_img = dp.g_input
+        # generator backward, in two programs: the PatchNCE feature pass's backward needs nothing from the discriminator ...
+        pg0 = Program("G-step (features backward)")
+        pg = Program("G-step")
         g_img, g_fold, g_img2 = g_adv_img, False, None
         if self.nce_layers:
-            pg.add(self.p2.bwd_program(hooks=hooks, accumulate=True, need_input_grad=True))
+            pg0.add(self.p2.bwd_program(hooks=hooks, accumulate=True, need_input_grad=True))
             g_img, g_fold, g_img2 = self.p2.g_input, True, g_adv_img
+        # ... the rest starts from the adversarial gradient
         pi = None
         if merged:
             # gradient wrt the 2B output images: [adversarial (+ folded PatchNCE input gradient) | identity L1 x identity weight]
@@ -481,7 +497,8 @@ class CutTrainer:
             pi.add(p3.bwd_program(g_idt, accumulate=True))
         pfo = Program("fake-out")
         pfo.add(ops.view_to_nchw(fake, 3, self.fake_out))
-        return {"p1": p1, "p3": p3, "photos_v": photos_v, "prog_gfwd": prog_gfwd, "prog_d_compute": pd, "prog_g_features": pf, "prog_g_compute": pg,
+        return {"p1": p1, "p3": p3, "photos_v": photos_v, "prog_gfwd": prog_gfwd, "prog_d_compute": pd, "prog_g_features": pf,
+                "prog_g_adversarial": pa, "prog_g_features_bwd": pg0, "prog_g_compute": pg,
                 "prog_g_identity": pi, "prog_fake_out": pfo}
 
     def _build_updates(self):
@@ -491,6 +508,7 @@ class CutTrainer:
         gs = 1.0 / self.world_size
         if getattr(self, "_r1_body", None) is None:
             # ---- lazy R1 (train_cutpp.py:165-203, 257-263), always fp32 like the reference
+            ops = self.opsD
             pr = Program("R1-body")
             rp, dnet = self.d_r1, self.D32
             pr.add(ops.nchw_to_view(self.photos, 3, rp.x, HALO_ZERO))
@@ -552,7 +570,7 @@ class CutTrainer:
             return dist.all_reduce(opt.flat_g, group=self.pg, async_op=True), None
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=self.device)
-        cur = torch.cuda.current_stream(self.device)
+        cur = opt.ctx.ops._ts()                                  # the stream the gradients were produced on
         self._comm_stream.wait_stream(cur)                       # the gradients are complete
         with torch.cuda.stream(self._comm_stream):
             work = dist.all_reduce(opt.flat_g, group=self.pg, async_op=True)
@@ -562,11 +580,33 @@ class CutTrainer:
         if handle is None:
             return
         work, cur = handle
-        work.wait()                                              # on CUDA: the compute stream waits for the collective, the host does not
-        if cur is not None:
-            cur.wait_stream(self._comm_stream)
+        if cur is None:
+            work.wait()
+            return
+        with torch.cuda.stream(cur):                             # the stream that produced the gradients (and will consume the
+            work.wait()                                          # reduced ones) waits for the collective; the host does not
+        cur.wait_stream(self._comm_stream)
 
     _comm_stream = None
+
+    # ---- the two events per step that order the main stream and the discriminator's stream
+    def _ev_fake_ready(self):
+        if self.opsD is self.ops:
+            return
+        if self._evA is None:
+            self._evA, self._evB = self.ops.new_event(), self.ops.new_event()
+        self._evA.record(self.ops._ts())
+        self.opsD._ts().wait_event(self._evA)
+
+    def _ev_adv_ready(self):
+        if self.opsD is not self.ops:
+            self._evB.record(self.opsD._ts())
+
+    def _ev_adv_wait(self):
+        if self.opsD is not self.ops:
+            self.ops._ts().wait_event(self._evB)
+
+    _evA, _evB = None, None
 
     def _allreduce(self, opt: FusedAdam):
         self._allreduce_finish(self._allreduce_start(opt))
@@ -591,15 +631,21 @@ class CutTrainer:
         self.losses.zero_()
         self.losses[LOSS_SLOTS["idw"]] = idw
         self.prog_gfwd.run()
+        self._ev_fake_ready()                       # main: G(photos) done   -> the discriminator's stream may start
+        # ---- discriminator's stream: D step, its all-reduce and update, lazy R1, then the adversarial gradient of the fake image
         self.prog_d_compute.run()
-        h = self._allreduce_start(self.opt_D)      # overlaps with the PatchNCE feature forward, which does not need D
-        self.prog_g_features.run()
-        self._allreduce_finish(h)
+        self._allreduce(self.opt_D)
         self.prog_d_update.run()
         if do_r1:
             self.prog_r1_compute.run()
             self._allreduce(self.opt_D)
             self.prog_r1_update.run()
+        self.prog_g_adversarial.run()
+        self._ev_adv_ready()                        # discriminator's stream: g_adv_img done -> main may build the output gradient
+        # ---- main stream, concurrently: PatchNCE feature pass forward and backward; then the rest of the generator step
+        self.prog_g_features.run()
+        self.prog_g_features_bwd.run()
+        self._ev_adv_wait()
         self.prog_g_compute.run()
         if idw > 0 and self.prog_g_identity is not None:
             self.prog_g_identity.run()
@@ -659,6 +705,7 @@ class CutTrainer:
     def checkpoint(self, step: int, metrics: Optional[dict] = None) -> dict:
         """The reference's checkpoint dict: generator / discriminator state_dicts (reference keys), torch.optim.Adam-layout optimiser
         states, {'decay','shadow'} EMA -- loadable by the reference's load_checkpoint and vice versa."""
+        self._device_sync()              # the discriminator's state is written on its own stream
         return {"step": step, "generator": {k: v.clone() for k, v in self.generator.state_dict().items()},
                 "discriminator": {k: v.clone() for k, v in self.discriminator.state_dict().items()},
                 "opt_G": _adam_state_dict(self.opt_G), "opt_D": _adam_state_dict(self.opt_D), "metrics": metrics or {}, "config": self.config,
@@ -686,8 +733,10 @@ class CutTrainer:
         if "ema_G" in ck and self.opt_G.flat_ema is not None:
             for k, v in ck["ema_G"]["shadow"].items():
                 self.opt_G.shadow[k].copy_(v)
+        self._device_sync()
         self.G.repack_program().run()
         self.D.repack_program().run()
+        self._device_sync()
         from . import autograd as AG
         AG.notify_weights_changed()
         return ck

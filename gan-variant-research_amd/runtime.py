@@ -174,6 +174,13 @@ class HipOps:
             self._side = HipOps(self.device, stream=ts.cuda_stream, torch_stream=ts)
         return self._side
 
+    def fork(self) -> "HipOps":
+        """A new op layer on its own (non-blocking) HIP stream of the same device (GAN_SINGLE_STREAM: this one)."""
+        if os.environ.get("GAN_SINGLE_STREAM"):
+            return self
+        ts = torch.cuda.Stream(device=self.device)
+        return HipOps(self.device, stream=ts.cuda_stream, torch_stream=ts)
+
     def _ts(self):
         return self.torch_stream if self.torch_stream is not None else torch.cuda.current_stream(self.device)
 

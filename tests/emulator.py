@@ -74,6 +74,12 @@ class EmuOps:
     def side(self):
         return self
 
+    def fork(self):
+        return self
+
+    def _ts(self):
+        return None
+
     def new_event(self):
         return None
 

@@ -31,7 +31,7 @@ torch.cuda.synchronize()
 
 rows = collections.OrderedDict()
 tot = 0.0
-for pname in ["prog_gfwd", "prog_d_compute", "prog_d_update", "prog_g_features", "prog_g_compute", "prog_g_identity", "prog_g_update"]:
+for pname in ["prog_gfwd", "prog_d_compute", "prog_d_update", "prog_g_features", "prog_g_adversarial", "prog_g_features_bwd", "prog_g_compute", "prog_g_identity", "prog_g_update"]:
     for op in (getattr(tr, pname).ops if getattr(tr, pname) is not None else []):
         for _ in range(2):
             op()
