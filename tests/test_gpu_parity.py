@@ -308,3 +308,37 @@ def test_conv_fused_instance_norm_statistics(bm, H, monkeypatch):
     ref = torch.nn.functional.conv2d(xc.padded().float().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), b)   # the halo is part of the view
     np.testing.assert_allclose(sg[..., 0].numpy(), ref.mean((2, 3)).numpy(), rtol=2e-3, atol=2e-3)
     np.testing.assert_allclose(sg[..., 1].numpy(), (1.0 / torch.sqrt(ref.var((2, 3), unbiased=False) + 1e-5)).numpy(), rtol=2e-3)
+
+
+def test_multi_stream_step_is_deterministic(monkeypatch):
+    """Three HIP streams per step (main, weight gradients, discriminator) and no atomics anywhere: two runs from the same seeds must
+    give bit-identical losses and weights -- a race between streams shows up here as run-to-run noise."""
+    from gan_variant_research_amd import cut as C
+    import bench
+    cfg = bench.default_config()
+    cfg["model"]["generator"]["ngf"], cfg["model"]["discriminator"]["ndf"] = 32, 32
+    cfg["r1"]["every"] = 2                               # R1 inside the window
+    B, S = 4, 128
+
+    def run():
+        C.set_seed(42)
+        gen, disc = C.build_models(cfg, DEV)
+        tr = C.CutTrainer(gen, disc, cfg, B, S, device=DEV, amp=True)
+        g = torch.Generator().manual_seed(3)
+        photos = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(DEV)
+        monets = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(DEV)
+        rg = torch.Generator().manual_seed(9)
+        out = []
+        for step in range(4):
+            out.append(tr.train_step(step, photos, monets, tr.sample_randomness(rg), sync="lag" if step % 2 else True))
+        out.append(tr.flush_losses())
+        torch.cuda.synchronize()
+        return [o for o in out if o is not None], tr.opt_G.flat_p.clone(), tr.opt_D.flat_p.clone()
+    la, ga, da = run()
+    lb, gb, db = run()
+    assert la == lb, (la, lb)
+    assert torch.equal(ga, gb) and torch.equal(da, db)
+    monkeypatch.setenv("GAN_SINGLE_STREAM", "1")          # the same launches on ONE stream: concurrency must not change a bit
+    lc, gc, dc = run()
+    assert la == lc, (la, lc)
+    assert torch.equal(ga, gc) and torch.equal(da, dc)
