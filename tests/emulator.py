@@ -99,7 +99,12 @@ class EmuOps:
         rows = min(256, m_img)
         wraps = (rows - 1) // c.Wo + 1
         jump = max(0, c.x.Wp * c.in_sy - c.Wo * c.in_sx)
-        return (rows - 1) * c.in_sx + wraps * jump + c.max_tapoff // c.Cin + 1 <= 448
+        if (rows - 1) * c.in_sx + wraps * jump + c.max_tapoff // c.Cin + 1 > 448:
+            return False
+        if c.B * (-(-m_img // 256)) <= 128:
+            return True
+        rows_used = min(-(-m_img // 256) * 256, -(-m_img // 288) * 288)       # tile utilisation >= 75 % once the CUs are full
+        return 4 * m_img >= 3 * rows_used
 
     def conv_stats_parts(self, c):
         """Statement of gan_conv_stats_parts; the emulator reports one part per image."""
@@ -164,6 +169,8 @@ class EmuOps:
         if c.x.dtype != 1 or c.ntaps != 9 or c.Cx % 64 or c.N % 128 or c.N != c.g.C:
             return 0
         if (c.x_sy, c.x_sx, c.g_sy, c.g_sx) != (1, 1, 1, 1) or c.Ho * c.Wo < 128:
+            return 0
+        if c.Ho * c.Wo < 8 * 128 and c.B > 64:      # many small images: short splits, B slabs to reduce
             return 0
         if c.Wo < 16 or c.Wo & (c.Wo - 1) or 128 % c.Wo or c.max_tapoff != (2 * c.x.Wp + 2) * c.Cx:
             return 0
