@@ -199,7 +199,7 @@ def main():
         ips = args.batch * world * args.steps / dt
         peak = PEAK_F32_TFLOPS if args.fp32 else PEAK_BF16_TFLOPS
         out = {
-            "metric": "images/sec (G+D train step) 256x256 CUT", "value": round(ips, 3), "unit": "images/s", "n_gpus": world,
+            "metric": f"images/sec (G+D train step) {args.size}x{args.size} CUT", "value": round(ips, 3), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
             "config": {"workload": f"CUT ResNet-9 G + PatchGAN D + PatchNCE + identity + lazy R1 + DiffAugment, {args.size}x{args.size}, "
