@@ -35,3 +35,24 @@ def test_missing_library_fails_loudly(tmp_path):
             _lib.load(str(tmp_path / "nope.so"))
     finally:
         _lib._lib = saved
+
+
+def test_argument_validation_messages():
+    """Every entry point validates before it launches: bad descriptors come back as a negative code with a message that names the
+    problem.  These calls fail in validation, so no GPU is touched."""
+    import ctypes as C
+    lib = _lib.load()
+    d = _lib.GanConvDesc()
+    d.dtype, d.B, d.Ho, d.Wo, d.Cin, d.ntaps, d.Nw, d.Nst = _lib.BF16, 1, 4, 4, 24, 9, 16, 8      # Cin not a power of two
+    assert lib.gan_conv_igemm(C.byref(d), None) < 0 and b"Cin=24" in lib.gan_last_error()
+    d.Cin, d.ntaps = 8, 9                                                                          # 9*8 is not a multiple of 64
+    assert lib.gan_conv_igemm(C.byref(d), None) < 0 and b"not a multiple" in lib.gan_last_error()
+    assert lib.gan_conv_patch_ok(C.byref(d)) == 0 and lib.gan_conv_patch_ok(None) == 0
+    w = _lib.GanWgradDesc()
+    assert lib.gan_wgrad_patch_splits(C.byref(w)) == 0
+    v = _lib.GanView()                                                                             # null view
+    assert lib.gan_in_stats(C.byref(v), C.c_float(1e-5), None, None, None) < 0 and lib.gan_last_error()
+    assert lib.gan_patchnce_ws_floats(2, 16, 64) == 3 * 2 * 16 * 64 + 3 * 2 * 16 + 4 + 64
+    assert lib.gan_adam_step(None, 0, None, None, 0, C.c_float(1e-3), C.c_float(0.5), C.c_float(0.999), C.c_float(1e-8), C.c_float(0), C.c_float(1),
+                             C.c_float(0), None, None, None) < 0
+    assert lib.gan_pack_weight_batch(None, 0, 0, None) < 0 and b"pack_weight_batch" in lib.gan_last_error()

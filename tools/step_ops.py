@@ -3,10 +3,13 @@
     python tools/step_ops.py [batch] [size] [--fp32]
 
 Convolution launches are priced in algorithmic FLOPs (2*B*Ho*Wo*Nst*Cin*ntaps); everything else is listed by time only.
-The sum differs a little from the step time because ops run back to back here with warm caches."""
+The sum differs from the step time: ops run back to back here with their operands cache-resident (a replayed HBM-bound launch reads
+optimistic: judge those by the in-step rocprofv3 profile), and the step overlaps three streams."""
 import collections
 import os
 import sys
+
+os.environ.setdefault("GAN_SINGLE_STREAM", "1")   # every launch on the one stream the HIP events below are recorded on
 
 import torch
 
