@@ -151,8 +151,21 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
-        pg = dist.group.WORLD
+        # RCCL prints its banner (host name, library path) on STDOUT when the communicator is created; the contract is ONE JSON
+        # line on stdout, so file descriptor 1 points at stderr until the communicator exists
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+            pg = dist.group.WORLD
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)                            # creates the communicator
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     from gan_variant_research_amd import cut as C
     cfg = default_config()
