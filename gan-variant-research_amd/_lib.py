@@ -94,6 +94,15 @@ class GanError(RuntimeError):
     pass
 
 
+def hip_runtimes_mapped():
+    """Distinct libamdhip64 files mapped into this process (Linux)."""
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({ln.split()[-1] for ln in f if "libamdhip64" in ln})
+    except OSError:
+        return []
+
+
 def load(path: str = LIB_PATH):
     """Loads the shared library once; raises GanError if it is absent or incomplete."""
     global _lib
@@ -102,7 +111,14 @@ def load(path: str = LIB_PATH):
     if not os.path.exists(path):
         raise GanError(f"{path} not found: build it with `make -C gan-variant-research_amd/csrc` "
                        "(or __graft_entry__.build()); there is no fallback path")
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Loaded after torch, this
+    # library binds to that copy and shares its device, streams and allocations; loaded first it would pull in /opt/rocm's copy,
+    # torch would then map its own beside it, and launches from here would fail with hipErrorNoDevice.
+    import torch  # noqa: F401
     lib = C.CDLL(path)
+    runtimes = hip_runtimes_mapped()
+    if len(runtimes) > 1:
+        raise GanError(f"two HIP runtimes mapped in this process ({', '.join(runtimes)}): import torch before loading {path}")
     for name, (res, args) in PROTOTYPES.items():
         try:
             fn = getattr(lib, name)

@@ -56,3 +56,15 @@ def test_argument_validation_messages():
     assert lib.gan_adam_step(None, 0, None, None, 0, C.c_float(1e-3), C.c_float(0.5), C.c_float(0.999), C.c_float(1e-8), C.c_float(0), C.c_float(1),
                              C.c_float(0), None, None, None) < 0
     assert lib.gan_pack_weight_batch(None, 0, 0, None) < 0 and b"pack_weight_batch" in lib.gan_last_error()
+
+
+def test_library_shares_the_hip_runtime_torch_uses():
+    """Loading the package before anything imported torch must still end with ONE libamdhip64 in the process: with two
+    (/opt/rocm's for this library, the wheel's for torch) launches from the library fail with hipErrorNoDevice."""
+    import subprocess
+    import sys
+    code = ("import gan_variant_research_amd as p; lib = p._lib.load(); import torch; "
+            "r = p._lib.hip_runtimes_mapped(); print(len(r), r); assert len(r) == 1, r")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
