@@ -1,0 +1,262 @@
+"""Geometry of one nn.Conv2d / nn.ConvTranspose2d on the generalised tap-convolution kernels.
+
+A ConvLayer owns the packed operand copies of one fp32 master weight (forward order and gradient order) and
+turns forward / input-gradient / weight-gradient requests on halo-NHWC views into ConvCall / WgradCall
+descriptors: which taps, which halo offsets, which sub-pixel phase.  All shape reasoning of the reference's
+convolutions (GAN_Variant1/models/generator_resnet_attn.py:33,48,113,125,146-149,160;
+discriminator_patchgan.py:27-51; Basic_GAN/src/models.py:12-103) lives here; the kernels only see descriptors.
+"""
+from __future__ import annotations
+
+import os
+
+from typing import List, Optional, Tuple
+
+import torch
+
+from ._lib import ACT_NONE, BF16, F32
+from .runtime import ConvCall, Ctx, View, WgradCall, cpad
+
+
+def _nw(n_real: int) -> int:
+    if n_real <= 16:
+        return 16
+    if n_real <= 64:
+        return 64
+    return (n_real + 127) // 128 * 128
+
+
+class _Pack:
+    """One packed operand copy [Nw][ntaps_pad][Cred] of a master weight plus its tap list."""
+
+    def __init__(self, ctx: Ctx, taps: List[Tuple[int, int, int]], n_real: int, c_real: int, swap: bool, i2: int, kk: int):
+        self.ctx, self.taps, self.n_real, self.c_real, self.swap, self.i2, self.kk = ctx, taps, n_real, c_real, swap, i2, kk
+        self.cred = cpad(c_real)
+        bke = 32 if ctx.dtype == F32 else 64
+        nt = len(taps)
+        while (nt * self.cred) % bke:
+            nt += 1
+        self.ntaps = nt
+        self.nw = _nw(n_real)
+        self.khw = ctx.i32([t[2] for t in taps] + [-1] * (nt - len(taps)))
+        self._w = None     # row-major copy (generic kernel), allocated on first use
+        self._wf = None    # fragment-major copy (range-patch kernel), allocated on first use
+        self._tapoff = {}
+
+    @property
+    def w(self) -> torch.Tensor:
+        if self._w is None:
+            self._w = torch.zeros(self.nw * self.ntaps * self.cred, dtype=self.ctx.tdtype, device=self.ctx.device)
+        return self._w
+
+    @property
+    def wf(self) -> torch.Tensor:
+        if self._wf is None:
+            self._wf = torch.zeros(self.nw * self.ntaps * self.cred, dtype=self.ctx.tdtype, device=self.ctx.device)
+        return self._wf
+
+    def pack_ops(self, master: torch.Tensor):
+        """Refreshes every operand copy that some planned call uses (plan all calls BEFORE building the repack program)."""
+        out = []
+        for buf, layout in ((self._w, 0), (self._wf, 1)):
+            if buf is not None:
+                out.append(self.ctx.ops.pack_weight(master, buf, self.ctx.dtype, self.nw, self.ntaps, self.cred, self.n_real, self.c_real,
+                                                    self.swap, self.i2, self.kk, self.khw, layout))
+        return out
+
+    def finalize(self, c: ConvCall) -> ConvCall:
+        """Picks the kernel for a planned call: range-patch (fragment-major weight copy) if it qualifies, else generic."""
+        c.w = None
+        if self.ctx.ops.conv_patch_ok(c):
+            c.w, c.w_frag = self.wf, True
+        else:
+            c.w, c.w_frag = self.w, False
+        return c
+
+    def tapoff(self, wp: int) -> torch.Tensor:
+        t = self._tapoff.get(wp)
+        if t is None:
+            t = self.ctx.i32([(dy * wp + dx) * self.cred for dy, dx, _ in self.taps] + [0] * (self.ntaps - len(self.taps)))
+            self._tapoff[wp] = t
+        return t
+
+    def max_tapoff(self, wp: int) -> int:
+        return max((dy * wp + dx) * self.cred for dy, dx, _ in self.taps)
+
+
+def _phase_taps(k: int, p: int, r: int):
+    """Transposed-conv / strided-dgrad taps of output parity r: [(kh, d)] with source index a + d."""
+    return [(kh, (r + p - kh) // 2) for kh in range(k) if (r + p - kh) % 2 == 0]
+
+
+class ConvLayer:
+    def __init__(self, ctx: Ctx, weight: torch.Tensor, bias: Optional[torch.Tensor], grad_w: torch.Tensor, grad_b: Optional[torch.Tensor],
+                 k: int, stride: int, pad: int, transposed: bool = False, need_dgrad: bool = True, need_wgrad: bool = True):
+        self.ctx, self.weight, self.bias, self.grad_w, self.grad_b = ctx, weight, bias, grad_w, grad_b
+        self.k, self.s, self.p, self.transposed = k, stride, pad, transposed
+        if transposed:
+            assert (k, stride, pad) == (3, 2, 1), "ConvTranspose2d is supported as k3 s2 p1 output_padding 1"
+            self.cin, self.cout = weight.shape[0], weight.shape[1]
+        else:
+            assert stride in (1, 2)
+            self.cout, self.cin = weight.shape[0], weight.shape[1]
+        kk = k * k
+        self.kk = kk
+        alltaps = [(kh, kw, kh * k + kw) for kh in range(k) for kw in range(k)]
+        self.packs: List[_Pack] = []
+        if not transposed:
+            self.fwd_pack = _Pack(ctx, alltaps, self.cout, self.cin, False, self.cin, kk)
+            self.packs.append(self.fwd_pack)
+            self.dgrad_packs = None
+            if need_dgrad:
+                if stride == 1:  # flipped taps over a zero-haloed dY
+                    taps = [(a, b, (k - 1 - a) * k + (k - 1 - b)) for a in range(k) for b in range(k)]
+                    self.dgrad_packs = [_Pack(ctx, taps, self.cin, self.cout, True, self.cin, kk)]
+                else:
+                    self.dgrad_packs = self._phase_packs(self.cin, self.cout, self.cin)
+                self.packs += self.dgrad_packs
+        else:
+            self.fwd_packs = self._phase_packs(self.cout, self.cin, self.cout)
+            self.packs += self.fwd_packs
+            self.dgrad_pack = None
+            if need_dgrad:  # strided conv over dY with the weight read as [out=cin][in=cout]
+                self.dgrad_pack = _Pack(ctx, alltaps, self.cin, self.cout, False, self.cout, kk)
+                self.packs.append(self.dgrad_pack)
+        self.need_wgrad = need_wgrad
+        # the epilogue reads bias[n] for every stored (padded) channel: keep a zero-padded copy when cout is not a multiple of 8
+        self.bias_k = bias
+        self._one = ctx.i32([0])
+        if bias is not None and cpad(self.cout) != self.cout:
+            self.bias_k = torch.zeros(_nw(self.cout), dtype=torch.float32, device=ctx.device)
+        self.wg_khw = ctx.i32([t[2] for t in alltaps])
+        self._wg_tapoff = {}
+
+    def _phase_packs(self, n_real, c_real, i2):
+        """Four sub-pixel phases (ry, rx); index [ry*2+rx] -> (_Pack, dmin_y, dmin_x)."""
+        out = []
+        for ry in range(2):
+            ty = _phase_taps(self.k, self.p, ry)
+            for rx in range(2):
+                tx = _phase_taps(self.k, self.p, rx)
+                dmy, dmx = min(d for _, d in ty), min(d for _, d in tx)
+                taps = [(dy - dmy, dx - dmx, kh * self.k + kw) for kh, dy in ty for kw, dx in tx]
+                pk = _Pack(self.ctx, taps, n_real, c_real, True, i2, self.kk)
+                pk.dmin, pk.dmax = (dmy, dmx), (max(d for _, d in ty), max(d for _, d in tx))
+                pk.phase = (ry, rx)
+                out.append(pk)
+        return out
+
+    # ------------------------------------------------------------------ weights
+    def repack_ops(self):
+        out = [op for pk in self.packs for op in pk.pack_ops(self.weight)]
+        if self.bias_k is not self.bias:
+            out.append(self.ctx.ops.pack_weight(self.bias, self.bias_k, F32, self.bias_k.numel(), 1, 1, self.cout, 1, False, 1, 1, self._one))
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def fwd(self, x: View, y: View, act: int = ACT_NONE, mask: Optional[View] = None, use_bias: bool = True,
+            stats_ws: Optional[torch.Tensor] = None):
+        """Forward launches.  stats_ws: if given and the launch can, its epilogue also writes the InstanceNorm partials of `y`
+        there; self.stats_parts then holds their count per image (0: not fused, the caller runs in_stats)."""
+        assert x.C == cpad(self.cin) and y.C == cpad(self.cout) and x.B == y.B, (x.C, self.cin, y.C, self.cout)
+        ops = self.ctx.ops
+        self.stats_parts = 0
+        if not self.transposed:
+            k, s, p = self.k, self.s, self.p
+            ho, wo = (x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1
+            assert (ho, wo) == (y.H, y.W) and x.halo >= p, (ho, wo, y.H, y.W, x.halo, p)
+            pk = self.fwd_pack
+            call = pk.finalize(ConvCall(x.B, ho, wo, pk.cred, pk.ntaps, pk.nw, min(pk.nw, y.C), x, x.halo - p, x.halo - p, s, s,
+                                        pk.tapoff(x.Wp), None, self.bias_k if use_bias else None, y, y.halo, y.halo, 1, 1, act, mask,
+                                        mask.halo if mask else 0, mask.halo if mask else 0, pk.max_tapoff(x.Wp)))
+            if stats_ws is not None and call.w_frag and call.Nst == y.C and not os.environ.get("GAN_NO_FUSED_STATS"):
+                n = ops.conv_stats_parts(call)
+                if 0 < n and x.B * n * y.C * 2 <= stats_ws.numel():
+                    call.stats, self.stats_parts = stats_ws, n
+            return [ops.conv_igemm(call)]
+        assert (y.H, y.W) == (2 * x.H, 2 * x.W)
+        return self._phased(self.fwd_packs, x, y, act, self.bias_k if use_bias else None, mask)
+
+    def _phased(self, packs, src: View, dst: View, act, bias, mask):
+        """dst[2a+r] = sum_taps src[a + d] * w: used by ConvTranspose2d forward and by the strided conv's input gradient."""
+        ops, out = self.ctx.ops, []
+        gh, gw = dst.H // 2, dst.W // 2
+        for pk in packs:
+            (ry, rx), (dmy, dmx), (dxy, dxx) = pk.phase, pk.dmin, pk.dmax
+            assert src.halo + dmy >= 0 and src.halo + dmx >= 0, "source halo too small (top/left)"
+            assert gh - 1 + dxy <= src.H - 1 + src.halo and gw - 1 + dxx <= src.W - 1 + src.halo, "source halo too small (bottom/right)"
+            out.append(ops.conv_igemm(pk.finalize(ConvCall(src.B, gh, gw, pk.cred, pk.ntaps, pk.nw, min(pk.nw, dst.C), src, src.halo + dmy, src.halo + dmx,
+                                               1, 1, pk.tapoff(src.Wp), None, bias, dst, dst.halo + ry, dst.halo + rx, 2, 2, act, mask,
+                                               (mask.halo + ry) if mask else 0, (mask.halo + rx) if mask else 0, pk.max_tapoff(src.Wp)))))
+        return out
+
+    # ------------------------------------------------------------------ input gradient
+    def dgrad(self, dy: View, dx: View, mask: Optional[View] = None, padded_domain: bool = False):
+        """dx <- dL/d(input).  padded_domain: also produce the gradient on the input's (reflect) halo; the consumer folds it."""
+        assert dy.C == cpad(self.cout) and dx.C == cpad(self.cin) and dy.B == dx.B
+        ops, k, p = self.ctx.ops, self.k, self.p
+        if self.transposed:  # regular strided conv over dy
+            pk = self.dgrad_pack
+            assert dy.halo >= p and (dy.H, dy.W) == (2 * dx.H, 2 * dx.W) and not padded_domain
+            return [ops.conv_igemm(pk.finalize(ConvCall(dy.B, dx.H, dx.W, pk.cred, pk.ntaps, pk.nw, min(pk.nw, dx.C), dy, dy.halo - p, dy.halo - p, 2, 2,
+                                            pk.tapoff(dy.Wp), None, None, dx, dx.halo, dx.halo, 1, 1, ACT_NONE, mask,
+                                            mask.halo if mask else 0, mask.halo if mask else 0, pk.max_tapoff(dy.Wp))))]
+        if self.s == 1:
+            pk = self.dgrad_packs[0]
+            if padded_domain:
+                assert dx.halo == p and dy.halo >= k - 1 and mask is None
+                gh, gw, oy, iy = dx.Hp, dx.Wp, 0, dy.halo - (k - 1)
+            else:
+                assert dy.halo >= k - 1 - p
+                gh, gw, oy, iy = dx.H, dx.W, dx.halo, dy.halo - (k - 1) + p
+            assert gh == dy.H + k - 1 - (0 if padded_domain else 2 * p), (gh, dy.H, k, p)
+            return [ops.conv_igemm(pk.finalize(ConvCall(dy.B, gh, gw, pk.cred, pk.ntaps, pk.nw, min(pk.nw, dx.C), dy, iy, iy, 1, 1, pk.tapoff(dy.Wp), None,
+                                            None, dx, oy, oy, 1, 1, ACT_NONE, mask, mask.halo if mask else 0, mask.halo if mask else 0, pk.max_tapoff(dy.Wp))))]
+        assert not padded_domain and (dx.H, dx.W) == (2 * dy.H, 2 * dy.W)
+        return self._phased(self.dgrad_packs, dy, dx, ACT_NONE, None, mask)
+
+    # ------------------------------------------------------------------ weight gradient
+    def _nsplit(self, m: int, jtiles: int, ntiles: int, ntiles_skinny: bool = False) -> int:
+        want = max(1, (1024 if ntiles_skinny else 512) // max(1, jtiles * ntiles))
+        ns = max(1, min(want, m // 512))
+        while ns > 1 and (ns - 1) * ((-(-m // ns) + 63) // 64 * 64) >= m:
+            ns -= 1
+        return ns
+
+    def wgrad(self, x: View, dy: View, accumulate: bool, bias_too: bool = True, ops=None):
+        """grad_w (+)= dL/dW from the layer input `x` and the output gradient `dy`.  ops: op layer to build the launches on
+        (default: the context's; the backward programs pass the second-stream layer)."""
+        ctx, k, p = self.ctx, self.k, self.p
+        ops = ctx.ops if ops is None else ops
+        epc = 4 if ctx.dtype == F32 else 8
+        if not self.transposed:
+            g, xo, stride = dy, x, self.s
+            assert x.halo >= p
+            n_real, c_real, i2 = self.cout, self.cin, self.cin
+        else:  # roles swap: rows run over the layer input, the "x operand" is dy
+            g, xo, stride = x, dy, 2
+            assert dy.halo >= p
+            n_real, c_real, i2 = self.cin, self.cout, self.cout
+        n, cx = g.C, xo.C
+        ktot = self.kk * cx
+        m = g.B * g.H * g.W
+        jt, ntl = 16 * epc, (16 if n <= 16 else (128 if ctx.dtype == BF16 else 64))
+        key = (xo.Wp, cx)
+        tapoff = self._wg_tapoff.get(key)
+        if tapoff is None:
+            tapoff = ctx.i32([(kh * xo.Wp + kw) * cx for kh in range(k) for kw in range(k)])
+            self._wg_tapoff[key] = tapoff
+        call = WgradCall(g.B, g.H, g.W, cx, self.kk, n, 1, xo, xo.halo - p, xo.halo - p, stride, stride, tapoff, g, g.halo, g.halo, 1, 1, None,
+                         max_tapoff=((k - 1) * xo.Wp + (k - 1)) * cx)
+        spi = ops.wgrad_patch_splits(call)
+        if spi > 0:      # range-patch kernel: splits never cross an image
+            call.nsplit, call.variant = g.B * spi, 1
+        else:
+            call.nsplit = self._nsplit(m, -(-ktot // jt), -(-n // ntl), n <= 16)
+        ns = call.nsplit
+        call.part = part = ctx.scratch("wgrad_part", ns * n * ktot)
+        out = [ops.conv_wgrad(call),
+               ops.wgrad_reduce(part, ns, n, self.kk, cx, n_real, c_real, False, i2, self.kk, self.wg_khw, self.grad_w, accumulate)]
+        if bias_too and self.grad_b is not None:
+            out.append(ops.bias_grad(dy, self.cout, self.grad_b, accumulate, ctx.scratch("bias_ws", 256 * max(dy.C, 256))))
+        return out

@@ -1,0 +1,543 @@
+// "Range-patch" implicit-GEMM convolution: the fast path of gan_conv_igemm for windows on narrow maps with >= 64 input
+// channels (the 18 residual 3x3 256->256 convolutions and their input gradients -- 40 % of the CUT step -- the
+// transposed-conv phases and the last discriminator layers).
+//
+// Measurements on gfx950 (profiles/) showed the generic kernel (conv_igemm.hip) is neither bandwidth- nor
+// bank-conflict-bound: its K-loop is LATENCY-bound by one block-wide barrier per 128-byte K-step around small dependent
+// LDS read batches, and a third of its time is per-tile prologue/epilogue.  This kernel is built around removing
+// synchronisation instead:
+//  * A operand: the pixels a 256-row tile needs for ALL taps form one contiguous range of the halo-NHWC image (GEMM rows
+//    are consecutive pixels, taps are constant pixel offsets).  One 64-channel slab of that range (<= 448 pixels x 128 B)
+//    is staged into LDS once and every tap reads its fragments from it at a shifted row -> ONE barrier per slab (288 MFMA
+//    per wave) instead of one per tap-step, and ~6x less global->LDS traffic for 3x3 windows;
+//  * W operand: never touches LDS.  The weights are packed "fragment-major" ([n/16][k/32][lane][8 bf16], see
+//    gan_pack_weight layout 1), so a wave fetches each MFMA A-fragment with one fully coalesced 1 KB global_load_dwordx4
+//    straight from L2/L1 into operand registers, prefetched one MFMA k-step ahead in a second register set;
+//  * one persistent 512-thread block per CU walks its tiles as one software pipeline: the next slab (or the next tile's
+//    first slab) is fetched to registers and written to the other LDS buffer while the current one computes, so tile
+//    boundaries cost no load latency.  Tile 256x128 (8 waves = 4(M) x 2(N), each 64x64 of v_mfma_f32_16x16x32_bf16) or
+//    288x128 (2 x 4 waves of 144x32), whichever needs fewer CU-rounds x rows; consecutive tiles of one pixel tile go to one XCD;
+//  * for exactly 9 taps the 256-row tile has a static schedule (NT = 9): unrolled tap loop, all fragment addresses of a tile
+//    precomputed, LDS buffer index folded into the ds_read immediate;
+//  * all global loads are plain VGPR loads (no LDS-DMA), so hipcc's counted s_waitcnt vmcnt(N) keeps the prefetch in flight;
+//  * the epilogue pairs lanes 16 apart (same pixel, adjacent channel quads) and writes 16-byte stores; optionally it also
+//    emits the InstanceNorm statistics of its tile (gan_conv_desc.stats) with DPP row reductions.
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+
+namespace {
+
+struct PatchArgs {
+  const char* in; const char* w; const float* bias; char* out; const char* mask; const int32_t* tapoff;
+  int B, M_img, Wo, MT_img, NTILES, tiles;
+  int Cin, nchunk, ntaps, KB;                             // KB = Ktot/32 fragment blocks per 16-row weight tile
+  int in_Hp, in_Wp, in_y0, in_x0, in_sy, in_sx, in_pix;   // in_pix: pixels in the whole input tensor
+  int out_Hp, out_Wp, out_C, out_y0, out_x0, out_sy, out_sx;
+  int Nst, act;
+  int mask_Hp, mask_Wp, mask_y0, mask_x0;
+  int w_bytes;
+  float* stats;                 // optional per-tile InstanceNorm partials [B][MT_img][out_C][2] (sum, sum of squares), plain stores
+  unsigned long long* stamps;   // diagnostic build only (GAN_PATCH_STAMPS): [block][32] s_memtime stamps of wave 0
+};
+
+constexpr int BN = 128, NTHR = 512;   // the tile height BM is a template parameter: 256 (4 x 2 waves of 64 x 64) or 288 (2 x 4 waves of 144 x 32)
+// 8 waves = (8/WGN) pixel groups x WGN channel groups.  Measured on the 3x3 256->256 layer (s_memtime stamps, cycles per
+// 64-channel slab): 4 x 2 (64 x 64 per wave) 15.5 k, 2 x 4 (128 x 32 per wave, half the weight bytes through the vector L1,
+// twice the LDS reads) 16.0 k; MFMA alone would be 9.2 k.  Neither operand path is the limiter: with two waves per SIMD each
+// 16x16x32 MFMA holds the SIMD's issue port for 8 of its 16 cycles, so the 30-odd non-MFMA instructions of a k-step do not
+// hide.  The 4 x 2 split is kept (shorter first slab, fewer address registers).
+// Tile 288 x 128 exists for tile-count quantisation: the 66x66 input-gradient domain is 4356 pixels per image = 18 tiles of 256
+// (576 tiles = 2.25 waves on 256 CUs -> 3 rounds) but 16 tiles of 288 (512 tiles -> 2 rounds of 1.125x the work: -25 %).
+constexpr int RMAX = 448;                    // pixels per patch buffer (7 slices of 64)
+constexpr int NSLICE = RMAX / 64;
+constexpr int PATCHB = RMAX * 128;
+constexpr int STATS_LDS = 8 * 128 * 2 * 4;    // per-wave (sum, sumsq) of up to 128 channels, combined across the pixel-split waves
+constexpr int LDS_BYTES = 2 * PATCHB + 512 + STATS_LDS;
+
+struct TileGeo { int b, m0, n0, P0; };
+
+// sum over the 16 lanes of a DPP row (every lane ends with the total): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float row16_sum(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});
+  v += dpp(v, std::integral_constant<int, 0x4E>{});
+  v += dpp(v, std::integral_constant<int, 0x141>{});
+  v += dpp(v, std::integral_constant<int, 0x140>{});
+  return v;
+}
+
+__device__ __forceinline__ int pixbase(const PatchArgs& a, int b, int m) {
+  const int ho = m / a.Wo, wo = m - ho * a.Wo;
+  return (b * a.in_Hp + ho * a.in_sy + a.in_y0) * a.in_Wp + wo * a.in_sx + a.in_x0;
+}
+template <int BM>
+__device__ __forceinline__ TileGeo tile_geo(const PatchArgs& a, int tau) {
+  TileGeo g;
+  const int mt = tau / a.NTILES;
+  g.n0 = (tau - mt * a.NTILES) * BN;
+  g.b = mt / a.MT_img;
+  g.m0 = (mt - g.b * a.MT_img) * BM;
+  g.P0 = pixbase(a, g.b, g.m0);
+  return g;
+}
+
+// NT > 0: static schedule for exactly NT taps and an even number of 64-channel slabs -- the tap loop is unrolled, tap offsets
+// live in scalar registers, the LDS buffer index is a compile-time constant (folded into the ds_read immediate) and, where
+// registers allow (FI <= 4), the swizzled fragment addresses of all taps are computed once per tile.  NT = 0: any tap count.
+template <int BM, int WGN, int NT>
+__global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
+  constexpr int FI = BM / (8 / WGN) / 16, FJ = BN / WGN / 16;   // fragments per wave: FI pixel groups x FJ channel groups
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  char* pbuf = lds;                       // [2][PATCHB]
+  int32_t* taptab = reinterpret_cast<int32_t*>(lds + 2 * PATCHB);
+  float* stsh = reinterpret_cast<float*>(lds + 2 * PATCHB + 512);   // [8 waves][16*FJ channels][2]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < a.ntaps; i += NTHR) taptab[i] = a.tapoff[i] / a.Cin;   // pixel offsets
+  int stoff[NT > 0 ? NT : 1];   // static schedule: pixel offset of every tap, wave-uniform
+  if constexpr (NT > 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) stoff[t] = __builtin_amdgcn_readfirstlane(a.tapoff[t] / a.Cin);
+  }
+  const int G = gridDim.x;
+  // XCD-aware start tile: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), and the NTILES channel tiles
+  // of one pixel tile (consecutive tau) read the same input patch -> give consecutive tau to workgroups of ONE XCD so the
+  // patch is fetched into one L2 once (PMC: 97 MB fetched per launch against 37 MB of input)
+  int tau = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (tau >= a.tiles) return;
+
+  // slab staging role: patch row r = 64*j + wave*8 + (lane>>3); LDS position p = lane&7 holds source chunk p ^ (r&7)
+  const int sr = wave * 8 + (lane >> 3), sp = lane & 7, sc = sp ^ (sr & 7);
+  const uint32_t pix_bytes = (uint32_t)a.Cin * 2u;
+  const uint32_t st_lds = (uint32_t)(sr * 128 + sp * 16);
+  auto slab_load = [&](const TileGeo& g, int chunk, int j) -> u32x4_t {
+    int srow = sr;
+    asm volatile("" : "+v"(srow));   // keeps the (unrolled) per-slice source addresses from being hoisted and spilled
+    int pix = g.P0 + 64 * j + srow;
+    pix = pix < a.in_pix ? pix : a.in_pix - 1;
+    return *reinterpret_cast<const u32x4_t*>(a.in + (size_t)((uint32_t)pix * pix_bytes + (uint32_t)(chunk * 128 + sc * 16)));
+  };
+  auto slab_store = [&](int buf, int j, const u32x4_t& v) {
+    *reinterpret_cast<u32x4_t*>(pbuf + buf * PATCHB + j * 8192 + st_lds) = v;
+  };
+
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int fr = lane & 15, fg = lane >> 4;
+  // weights, fragment-major: byte offset of (n16, kb, lane) = ((n16*KB + kb)*64 + lane)*16
+  // weights through a buffer descriptor: voffset = lane*16 (constant), everything else is a wave-uniform scalar offset,
+  // so a weight fetch costs no vector ALU work at all
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+  const int lane16 = lane * 16;
+  const int wn_u = __builtin_amdgcn_readfirstlane(wn);
+  auto w_load = [&](int n0_tile, int kb, u32x4_t (&f)[FJ]) {   // one MFMA k-step (32 channels) of this wave's weight rows
+    const int base = __builtin_amdgcn_readfirstlane((((n0_tile + wn_u * (16 * FJ)) >> 4) * a.KB + kb) * 1024);   // provably wave-uniform: no waterfall
+#pragma unroll
+    for (int j = 0; j < FJ; ++j)
+      f[j] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, base + j * a.KB * 1024, 0));
+  };
+  const bool dbg_w0 = a.stamps && ((uintptr_t)a.stamps & 2);   // diagnostic: every weight fetch reads block 0 (L1-resident)
+  auto kb_of = [&](int c, int t) { return dbg_w0 ? 0 : (t * a.Cin + c * 64) >> 5; };
+
+  int nstamp = 0;
+  auto stamp = [&]() {
+    if (a.stamps && wave == 0 && nstamp < 32) {
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      if (lane == 0) ((unsigned long long*)((uintptr_t)a.stamps & ~(uintptr_t)7))[blockIdx.x * 32 + nstamp] = t;
+      ++nstamp;
+    }
+  };
+  stamp();
+  TileGeo g = tile_geo<BM>(a, tau);
+  // prologue: first slab -> LDS buffer 0, first tap's weights -> registers
+  {
+    u32x4_t tmp[NSLICE];
+#pragma unroll
+    for (int j = 0; j < NSLICE; ++j) tmp[j] = slab_load(g, 0, j);
+#pragma unroll
+    for (int j = 0; j < NSLICE; ++j) slab_store(0, j, tmp[j]);
+  }
+  u32x4_t Wa[FJ], Wb[FJ], Xa[FI], Xb[FI];   // operand fragments of the even / odd k-step of a tap
+  w_load(g.n0, kb_of(0, 0), Wa);
+  __syncthreads();   // tap table + slab 0 visible
+  stamp();
+
+  int pcur = 0;
+  while (true) {
+    int lbase[FI];
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+      int m = g.m0 + wm * (16 * FI) + i * 16 + fr;
+      m = m < a.M_img ? m : a.M_img - 1;
+      lbase[i] = pixbase(a, g.b, m) - g.P0;
+    }
+    const int tau_next = tau + G;
+    const bool has_next = tau_next < a.tiles;
+    TileGeo gn = g;
+    if (has_next) gn = tile_geo<BM>(a, tau_next);
+
+    f32x4_t acc[FI][FJ];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // 16 MFMAs of one k-step in two parts, so that the next k-step's fetches can be issued AFTER the waits that guard this
+    // k-step's operands (a wait placed before the first MFMA would otherwise also cover the fetches just issued)
+    auto mma_part = [&](const u32x4_t (&wf)[FJ], const u32x4_t (&xf)[FI], int i0, int i1) {
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+        if (i >= i0 && i < i1) {
+#pragma unroll
+          for (int j = 0; j < FJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[j]), __builtin_bit_cast(bf16x8_t, xf[i]), acc[i][j], 0, 0, 0);
+        }
+    };
+    if constexpr (NT > 0) {
+      constexpr bool PRE = FI <= 4;
+      uint32_t xa[PRE ? NT : 1][FI];
+      if constexpr (PRE) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < FI; ++i) {
+            const int prow = lbase[i] + stoff[t];
+            xa[t][i] = (uint32_t)(prow * 128 + ((fg ^ (prow & 7)) << 4));
+          }
+      }
+      const int cin32 = a.Cin >> 5;
+      auto static_slab = [&](auto pc_tag, int c) {
+        constexpr int PC = decltype(pc_tag)::value;
+        const bool last_chunk = c + 1 == a.nchunk;
+        const bool stage_next = !last_chunk || has_next;
+        const TileGeo gs = last_chunk ? gn : g;
+        const int cs = last_chunk ? 0 : c + 1;
+        const char* pb = pbuf + PC * PATCHB;
+        u32x4_t stg = {0, 0, 0, 0};
+        // hipcc hoists loop-invariant per-lane addresses out of the (unrolled) loops and then spills them: the values that
+        // feed the address arithmetic are made opaque where they are used
+        auto x_load = [&](int t, int kq, u32x4_t (&xf)[FI]) {
+          uint32_t flip = kq ? 64u : 0u;
+          if (kq) asm volatile("" : "+v"(flip));
+#pragma unroll
+          for (int i = 0; i < FI; ++i) {
+            uint32_t ad;
+            if constexpr (PRE) ad = xa[t][i];
+            else {
+              int lb = lbase[i];
+              asm volatile("" : "+v"(lb));
+              const int prow = lb + stoff[t];
+              ad = (uint32_t)(prow * 128 + ((fg ^ (prow & 7)) << 4));
+            }
+            xf[i] = *reinterpret_cast<const u32x4_t*>(pb + (ad ^ flip));
+          }
+        };
+        x_load(0, 0, Xa);   // Wa was fetched by the previous slab's last step (or the prologue)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int kb_cur = t * cin32 + 2 * c;
+          __builtin_amdgcn_sched_barrier(0);
+          mma_part(Wa, Xa, 0, FI / 4);
+          __builtin_amdgcn_sched_barrier(0);
+          w_load(g.n0, kb_cur + 1, Wb);
+          x_load(t, 1, Xb);
+          if (stage_next) {
+            if (t >= 1 && t <= NSLICE) slab_store(PC ^ 1, t - 1, stg);
+            if (t < NSLICE) stg = slab_load(gs, cs, t);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mma_part(Wa, Xa, FI / 4, FI);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_part(Wb, Xb, 0, FI / 4);
+          __builtin_amdgcn_sched_barrier(0);
+          if (t + 1 < NT) {
+            w_load(g.n0, kb_cur + cin32, Wa);
+            x_load(t + 1, 0, Xa);
+          } else {   // first tap of the next slab, or of the next tile (after the very last tap: a harmless re-read)
+            w_load(last_chunk ? gn.n0 : g.n0, last_chunk ? 0 : 2 * (c + 1), Wa);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mma_part(Wb, Xb, FI / 4, FI);
+        }
+        static_assert(NT > NSLICE, "the static schedule stages one slice per tap");
+        __syncthreads();   // every wave is done with this slab; the other buffer is completely written
+        stamp();
+      };
+      for (int c = 0; c < a.nchunk; c += 2) {   // nchunk is even: every tile starts on buffer 0
+        static_slab(std::integral_constant<int, 0>{}, c);
+        static_slab(std::integral_constant<int, 1>{}, c + 1);
+      }
+    } else
+    for (int c = 0; c < a.nchunk; ++c) {
+      const bool last_chunk = c + 1 == a.nchunk;
+      const bool stage_next = !last_chunk || has_next;
+      const TileGeo gs = last_chunk ? gn : g;   // owner of the next slab
+      const int cs = last_chunk ? 0 : c + 1;
+      const char* pb = pbuf + pcur * PATCHB;
+      u32x4_t stg = {0, 0, 0, 0};
+      int sj = 0;          // next slice to fetch; slice sj-1 is in `stg` waiting to be written
+
+      // A fragments of one k-step of tap t: 4 x ds_read_b128 from the slab at the tap's row shift.  The second k-step's
+      // chunk index differs by 4, i.e. its swizzled address is the first one's XOR 64.
+      uint32_t xaddr[FI];
+      auto x_addr = [&](int toff) {
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+          const int prow = lbase[i] + toff;
+          xaddr[i] = (uint32_t)(prow * 128 + ((fg ^ (prow & 7)) << 4));
+        }
+      };
+      auto x_load = [&](int kq, u32x4_t (&xf)[FI]) {
+#pragma unroll
+        for (int i = 0; i < FI; ++i) xf[i] = *reinterpret_cast<const u32x4_t*>(pb + (xaddr[i] ^ (kq ? 64u : 0u)));
+      };
+      x_addr(taptab[0]);
+      x_load(0, Xa);   // Wa was fetched by the previous slab's last step (or the prologue)
+      for (int t = 0; t < a.ntaps; ++t) {
+        // where the NEXT tap's weights live: next tap, else first tap of the next slab, else of the next tile (branch-free scalars;
+        // after the very last tap this re-reads the current tile's first block, harmlessly)
+        const bool last_tap = t + 1 == a.ntaps;
+        const int nt = last_tap ? 0 : t + 1;
+        const int nc = last_tap ? (last_chunk ? 0 : c + 1) : c;
+        const int nn0 = (last_tap && last_chunk) ? gn.n0 : g.n0;
+        const int kb_cur = kb_of(c, t), kb_next = kb_of(nc, nt);
+
+        __builtin_amdgcn_sched_barrier(0);
+        mma_part(Wa, Xa, 0, FI / 4);                 // waits for Wa / Xa (issued one k-step ago) land here
+        __builtin_amdgcn_sched_barrier(0);
+        w_load(g.n0, kb_cur + 1, Wb);
+        x_load(1, Xb);
+        const int toff_next = taptab[last_tap ? t : t + 1];   // fetched a half step before x_addr needs it
+        if (stage_next) {
+          if (sj > 0 && sj <= NSLICE) slab_store(pcur ^ 1, sj - 1, stg);
+          if (sj < NSLICE) stg = slab_load(gs, cs, sj);
+          ++sj;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_part(Wa, Xa, FI / 4, FI);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_part(Wb, Xb, 0, FI / 4);
+        __builtin_amdgcn_sched_barrier(0);
+        w_load(nn0, kb_next, Wa);
+        if (!last_tap) { x_addr(toff_next); x_load(0, Xa); }   // the next slab's activations wait for the barrier
+        __builtin_amdgcn_sched_barrier(0);
+        mma_part(Wb, Xb, FI / 4, FI);
+      }
+      // flush the slices the taps did not get to (few-tap layers), then hand the buffer over
+      if (stage_next) {
+        while (sj <= NSLICE) {
+          if (sj > 0) slab_store(pcur ^ 1, sj - 1, stg);
+          if (sj < NSLICE) stg = slab_load(gs, cs, sj);
+          ++sj;
+        }
+      }
+      __syncthreads();   // every wave is done with slab `pcur`; slab `pcur^1` is completely written
+      pcur ^= 1;
+      stamp();
+    }
+
+    // ---- epilogue (the next tile's slab is in LDS and its first weights are in flight).  Specialised on the activation at
+    // compile time: with a run-time switch per value the 64 results per lane made this phase VALU-bound (8.4k cycles).
+    auto epilogue = [&](auto act_tag, auto mask_tag, auto stats_tag) {
+      constexpr int ACT = decltype(act_tag)::value;
+      constexpr bool MASK = decltype(mask_tag)::value;
+      constexpr bool STATS = decltype(stats_tag)::value;
+      float ssum[STATS ? 4 * FJ : 1], ssq[STATS ? 4 * FJ : 1];
+      if constexpr (STATS) {
+#pragma unroll
+        for (int q = 0; q < 4 * FJ; ++q) ssum[q] = ssq[q] = 0.f;
+      }
+      bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
+      const bf16_t* mask = reinterpret_cast<const bf16_t*>(a.mask);
+      f32x4_t bq[FJ];   // bias of this lane's channel quads
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) {
+        const int n = g.n0 + wn * (16 * FJ) + j * 16 + fg * 4;
+        bq[j] = (a.bias && n < a.Nst) ? *reinterpret_cast<const f32x4_t*>(a.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+      const bool odd = fg & 1;
+#pragma unroll
+      for (int i = 0; i < FI; ++i) {
+        const int m = g.m0 + wm * (16 * FI) + i * 16 + fr;
+        const bool mok = m < a.M_img;
+        const int mm = mok ? m : a.M_img - 1;
+        const int ho = mm / a.Wo, wo = mm - ho * a.Wo;
+        const int64_t ob = ((int64_t)(g.b * a.out_Hp + ho * a.out_sy + a.out_y0) * a.out_Wp + wo * a.out_sx + a.out_x0) * a.out_C;
+        u32x2_t pk[FJ];
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = acc[i][j][e] + bq[j][e];
+            if constexpr (STATS) { const float tm = mok ? t : 0.f; ssum[4 * j + e] += tm; ssq[4 * j + e] += tm * tm; }
+            v[e] = ACT == GAN_ACT_RELU ? fmaxf(t, 0.f) : ACT == GAN_ACT_LRELU ? (t > 0.f ? t : 0.2f * t) : ACT == GAN_ACT_TANH ? tanhf(t) : t;
+          }
+          if (MASK) {
+            const int n = g.n0 + wn * (16 * FJ) + j * 16 + fg * 4;
+            if (n < a.Nst) {
+              const int64_t mb = ((int64_t)(g.b * a.mask_Hp + ho * a.out_sy + a.mask_y0) * a.mask_Wp + wo * a.out_sx + a.mask_x0) * a.out_C;
+              const u32x2_t mv = *reinterpret_cast<const u32x2_t*>(mask + mb + n);
+              v[0] *= (bf2f((bf16_t)(mv[0] & 0xffff)) > 0.f ? 1.f : 0.2f); v[1] *= (bf2f((bf16_t)(mv[0] >> 16)) > 0.f ? 1.f : 0.2f);
+              v[2] *= (bf2f((bf16_t)(mv[1] & 0xffff)) > 0.f ? 1.f : 0.2f); v[3] *= (bf2f((bf16_t)(mv[1] >> 16)) > 0.f ? 1.f : 0.2f);
+            }
+          }
+          pk[j][0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          pk[j][1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        }
+        // lanes 16 apart hold the same pixel and adjacent channel quads: of each pair of channel tiles even fg keeps the first
+        // and odd fg the second; each sends the quad of the tile it does not keep -> one 16-byte run per lane and tile pair
+#pragma unroll
+        for (int jp = 0; jp < FJ / 2; ++jp) {
+          const uint32_t s0 = odd ? pk[2 * jp][0] : pk[2 * jp + 1][0], s1 = odd ? pk[2 * jp][1] : pk[2 * jp + 1][1];
+          const uint32_t r0 = (uint32_t)__shfl_xor((int)s0, 16, 64), r1 = (uint32_t)__shfl_xor((int)s1, 16, 64);
+          u32x4_t st;
+          if (!odd) { st[0] = pk[2 * jp][0]; st[1] = pk[2 * jp][1]; st[2] = r0; st[3] = r1; }
+          else      { st[0] = r0; st[1] = r1; st[2] = pk[2 * jp + 1][0]; st[3] = pk[2 * jp + 1][1]; }
+          const int nst = g.n0 + wn * (16 * FJ) + (2 * jp + (odd ? 1 : 0)) * 16 + (fg & 2) * 4;
+          if (mok && nst < a.Nst) *reinterpret_cast<u32x4_t*>(out + ob + nst) = st;
+        }
+      }
+      if constexpr (STATS) {
+        // InstanceNorm partials of this tile: over the 16 pixel lanes of a lane group, then over the pixel-split waves in a
+        // fixed order (deterministic: no atomics), one float2 per channel to stats[b][m-tile][n]
+        // row (16-lane) all-reduce with DPP modifiers on the adds -- vector ALU only; __shfl_xor lowers to ds_bpermute and 256 of
+        // those per wave cost 8 us per launch, as much as the statistics pass they replace
+#pragma unroll
+        for (int q = 0; q < 4 * FJ; ++q) { ssum[q] = row16_sum(ssum[q]); ssq[q] = row16_sum(ssq[q]); }
+        if (fr == 0) {
+#pragma unroll
+          for (int q = 0; q < 4 * FJ; ++q) {
+            const int ch = (q >> 2) * 16 + fg * 4 + (q & 3);           // channel inside this wave's 16*FJ
+            *reinterpret_cast<float2*>(stsh + ((wave * (16 * FJ) + ch) << 1)) = make_float2(ssum[q], ssq[q]);
+          }
+        }
+        __syncthreads();
+        constexpr int WM = 8 / WGN;
+        if (tid < BN) {
+          const int cwn = tid / (16 * FJ), cch = tid % (16 * FJ);
+          float2 tot = make_float2(0.f, 0.f);
+#pragma unroll
+          for (int m = 0; m < WM; ++m) {
+            const float2 v2 = *reinterpret_cast<const float2*>(stsh + (((m * WGN + cwn) * (16 * FJ) + cch) << 1));
+            tot.x += v2.x; tot.y += v2.y;
+          }
+          const int n = g.n0 + tid;
+          if (n < a.Nst)
+            *reinterpret_cast<float2*>(a.stats + (((int64_t)g.b * a.MT_img + g.m0 / BM) * a.out_C + n) * 2) = tot;
+        }
+        __syncthreads();   // stsh is rewritten by the next tile
+      }
+    };
+    using std::integral_constant;
+    if (a.mask) epilogue(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, true>{}, integral_constant<bool, false>{});   // LeakyReLU' masks only follow plain dgrads
+    else if (a.act == GAN_ACT_NONE && a.stats) epilogue(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, false>{}, integral_constant<bool, true>{});
+    else if (a.act == GAN_ACT_NONE) epilogue(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
+    else if (a.act == GAN_ACT_LRELU) epilogue(integral_constant<int, GAN_ACT_LRELU>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
+    else if (a.act == GAN_ACT_RELU) epilogue(integral_constant<int, GAN_ACT_RELU>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
+    else epilogue(integral_constant<int, GAN_ACT_TANH>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
+
+    stamp();
+    if (!has_next) break;
+    tau = tau_next;
+    g = gn;
+  }
+}
+
+}  // namespace
+
+// pixels of the contiguous input range a tile of BM output pixels reads (all taps)
+static int patch_span(const gan_conv_desc* d, int BM) {
+  const int M_img = d->Ho * d->Wo;
+  const int maxtap = d->max_tapoff / d->Cin;
+  const int rows = BM < M_img ? BM : M_img;
+  const int wraps = (rows - 1) / d->Wo + 1;
+  const int jump = d->in_Wp * d->in_sy - d->Wo * d->in_sx;
+  return (rows - 1) * d->in_sx + wraps * (jump > 0 ? jump : 0) + maxtap + 1;
+}
+
+// tile height: the one that needs the fewest CU-rounds x rows (GAN_PATCH_BM forces one; tuning aid, read per call so a test can toggle it)
+static int patch_tile_rows(const gan_conv_desc* d) {
+  const int M_img = d->Ho * d->Wo, ncu = 256;
+  int BM = 0, forced = 0;
+  int64_t best = 0;
+  { const char* e = getenv("GAN_PATCH_BM"); forced = e ? atoi(e) : 0; }
+  for (int cand : {256, 288}) {
+    if (patch_span(d, cand) > RMAX || (forced && forced != cand && patch_span(d, forced) <= RMAX)) continue;
+    const int64_t tiles = (int64_t)d->B * ((M_img + cand - 1) / cand) * ((d->Nst + BN - 1) / BN);
+    const int64_t cost = ((tiles + ncu - 1) / ncu) * cand;
+    if (!BM || cost < best) { BM = cand; best = cost; }
+  }
+  return BM;
+}
+
+// Pure predicate (no device access): does this descriptor qualify for the range-patch kernel?  The planner asks at
+// build time because qualifying calls need the fragment-major weight packing (gan_pack_weight layout 1).
+extern "C" int gan_conv_patch_ok(const gan_conv_desc* d) {
+  static int disabled = -1;
+  if (disabled < 0) { const char* e = getenv("GAN_NO_PATCH"); disabled = (e && atoi(e)) ? 1 : 0; }
+  if (disabled || !d) return 0;
+  if (d->mask && d->act != GAN_ACT_NONE) return 0;   // the masked epilogue is specialised for act = none
+  if (d->dtype != GAN_BF16 || d->Cin < 64 || d->Cin % 64 != 0 || d->Nw % BN != 0 || d->Nst % 8 != 0 || d->out_C % 8 != 0) return 0;
+  if (d->max_tapoff <= 0 || d->ntaps < 1) return 0;
+  if (!(patch_span(d, 256) <= RMAX || patch_span(d, 288) <= RMAX)) return 0;
+  // tile utilisation: a map of 324 pixels (18x18 input-gradient domain of a 16x16 layer) fills 63 % of two 256-row tiles -- the
+  // generic kernel's 128-row tiles waste less there (Basic_GAN at 64x64: +5 % with it)
+  const int M_img = d->Ho * d->Wo;
+  const int t256 = (M_img + 255) / 256 * 256, t288 = (M_img + 287) / 288 * 288;
+  const int rows = t256 < t288 ? t256 : t288;
+  if (d->B * ((M_img + 255) / 256) <= 128) return 1;   // few tiles: the CUs are not full either way
+  return 4 * M_img >= 3 * rows ? 1 : 0;
+}
+
+// InstanceNorm partials per image the range-patch kernel writes to d->stats ([B][parts][out_C][2]); 0: this descriptor cannot fuse them
+extern "C" int gan_conv_stats_parts(const gan_conv_desc* d) {
+  if (!gan_conv_patch_ok(d) || d->act != GAN_ACT_NONE || d->mask || d->out_sy != 1 || d->out_sx != 1) return 0;
+  const int BM = patch_tile_rows(d);
+  return (d->Ho * d->Wo + BM - 1) / BM;
+}
+
+int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
+  if (!gan_conv_patch_ok(d)) return gan_set_error(-1, "conv: w_layout=1 (fragment-major weights) but the descriptor does not qualify for the range-patch kernel");
+  PatchArgs a;
+  const int M_img = d->Ho * d->Wo;
+  const int ncu = 256;
+  const int BM = patch_tile_rows(d);
+  a.in = (const char*)d->in; a.w = (const char*)d->w; a.bias = d->bias; a.out = (char*)d->out; a.mask = (const char*)d->mask; a.tapoff = d->tapoff;
+  a.B = d->B; a.M_img = M_img; a.Wo = d->Wo; a.MT_img = (M_img + BM - 1) / BM; a.NTILES = (d->Nst + BN - 1) / BN;
+  a.tiles = a.B * a.MT_img * a.NTILES;
+  a.Cin = d->Cin; a.nchunk = d->Cin / 64; a.ntaps = d->ntaps; a.KB = d->ntaps * d->Cin / 32;
+  a.w_bytes = d->Nw * d->ntaps * d->Cin * 2;
+  a.in_Hp = d->in_Hp; a.in_Wp = d->in_Wp; a.in_y0 = d->in_y0; a.in_x0 = d->in_x0; a.in_sy = d->in_sy; a.in_sx = d->in_sx;
+  a.in_pix = d->B * d->in_Hp * d->in_Wp;
+  a.out_Hp = d->out_Hp; a.out_Wp = d->out_Wp; a.out_C = d->out_C; a.out_y0 = d->out_y0; a.out_x0 = d->out_x0; a.out_sy = d->out_sy; a.out_sx = d->out_sx;
+  a.Nst = d->Nst; a.act = d->act; a.stats = d->stats;
+  if (d->stats && (d->act != GAN_ACT_NONE || d->mask)) return gan_set_error(-1, "conv: fused statistics need act = none and no mask");
+  a.mask_Hp = d->mask_Hp; a.mask_Wp = d->mask_Wp; a.mask_y0 = d->mask_y0; a.mask_x0 = d->mask_x0;
+  { const char* e = getenv("GAN_PATCH_STAMPS"); a.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
+  const int grid = a.tiles < ncu ? a.tiles : ncu;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv_patch_kernel<256, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv_patch_kernel<288, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv_patch_kernel<256, 2, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+      return gan_set_error(-2, "conv_patch: cannot raise the dynamic LDS limit to %d bytes", LDS_BYTES);
+    attr_set = true;
+  }
+  // The static 3x3 schedule, 256-row tile only.  Measured (s_memtime): 15.5 k -> 13.0 k cycles per slab, but the denser issue
+  // stream clocks lower (2.04 -> 1.88 GHz), so the forward gains 3 % wall (69.5 -> 67.2 us = 1.15 PFLOP/s); on the 288-row tile,
+  // whose 9 fragment addresses per tap do not fit in registers, it lost 9 % and is not instantiated.
+  bool st9 = BM == 256 && d->ntaps == 9 && a.nchunk % 2 == 0;
+  { const char* e = getenv("GAN_PATCH_STATIC"); if (e && !atoi(e)) st9 = false; }
+  if (BM == 256) {
+    if (st9) hipLaunchKernelGGL((conv_patch_kernel<256, 2, 9>), dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((conv_patch_kernel<256, 2, 0>), dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
+  } else {
+    hipLaunchKernelGGL((conv_patch_kernel<288, 4, 0>), dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
+  }
+  if (hipGetLastError() != hipSuccess) return gan_set_error(-2, "conv_patch: launch failed");
+  return 0;
+}

@@ -363,23 +363,9 @@ class CutTrainer:
         self.photos, self.monets = self.both[:B], self.both[B:]
         self.fake_out = torch.zeros_like(self.photos)
         self.losses = f32(16)
+        self.prm = {k: f32(B * 12) for k in ("real", "fake_d", "fake_g")}
         self.nce_hw = [(S >> (0 if i == 0 else 1 if i == 1 else 2 if i < 3 + nb else 1 if i == 3 + nb else 0)) ** 2 for i in self.nce_layers]
-        # every per-step random draw (3 DiffAugment tables, PatchNCE ids) lives in ONE device block filled by ONE non-blocking copy
-        # from pinned memory: seven small pageable copies would each stall the host until the stream drains (measured: 7 idle gaps
-        # of ~0.1 ms per step and no host lead over the GPU)
-        seg = [B * 12] * 3 + [min(self.P, hw) for hw in self.nce_hw]
-        offs = [0]
-        for n in seg:
-            offs.append(offs[-1] + (n + 63) // 64 * 64)
-        self._rnd_dev = torch.zeros(offs[-1], dtype=torch.int32, device=self.device)
-        self._rnd_host = [torch.zeros(offs[-1], dtype=torch.int32, pin_memory=self.device.type == "cuda") for _ in range(2)]
-        self._rnd_events = [None, None]
-        self._rnd_turn = 0
-        cut = lambda t, i: t[offs[i]:offs[i] + seg[i]]
-        self.prm = {k: cut(self._rnd_dev, i).view(torch.float32) for i, k in enumerate(("real", "fake_d", "fake_g"))}
-        self.nce_ids = [cut(self._rnd_dev, 3 + i) for i in range(len(self.nce_hw))]
-        self._rnd_host_views = [({k: cut(h, i).view(torch.float32) for i, k in enumerate(("real", "fake_d", "fake_g"))},
-                                 [cut(h, 3 + i) for i in range(len(self.nce_hw))]) for h in self._rnd_host]
+        self.nce_ids = [torch.zeros(min(self.P, hw), dtype=torch.int32, device=self.device) for hw in self.nce_hw]
         self._modes = {}
         self._use_mode(self.merge_identity and identity_weight_at(0, config) > 0)
 
@@ -568,21 +554,11 @@ class CutTrainer:
 
     def _load_randomness(self, rnd: dict):
         B, S = self.B, self.S
-        i = self._rnd_turn
-        self._rnd_turn ^= 1
-        if self._rnd_events[i] is not None:
-            self._rnd_events[i].synchronize()          # the copy that last read this pinned block (two steps ago) has run
-        prm, ids_h = self._rnd_host_views[i]
         if self.aug is not None:
             for key, k in (("real", "aug_real"), ("fake_d", "aug_fake_d"), ("fake_g", "aug_fake_g")):
-                prm[key].copy_(DiffAugment.to_params(rnd[k], B, S, S).reshape(-1))
-        for dst, ids in zip(ids_h, rnd["nce_ids"]):
-            dst.copy_(ids)
-        self._rnd_dev.copy_(self._rnd_host[i], non_blocking=True)
-        if self.device.type == "cuda":
-            if self._rnd_events[i] is None:
-                self._rnd_events[i] = torch.cuda.Event()
-            self._rnd_events[i].record()
+                self.prm[key].copy_(DiffAugment.to_params(rnd[k], B, S, S).reshape(-1))
+        for dst, ids in zip(self.nce_ids, rnd["nce_ids"]):
+            dst.copy_(ids.to(torch.int32))
 
     def _allreduce_start(self, opt: FusedAdam):
         """Launches the gradient all-reduce (sum; the optimiser divides by world_size) of one flat block on the communication

@@ -1,0 +1,198 @@
+/*
+ * mi355x_gan.h -- C ABI of libmi355x_gan.so: the MI355X (gfx950) GAN training inner loop.
+ *
+ * The reference (Cameronr11/GAN-Variant-Research) has no FFI of its own: its operator API is
+ * torch.nn -> ATen.  Each entry point below replaces the ATen ops one reference call site dispatches
+ * (cited as file:line relative to the reference root).  All pointers are DEVICE pointers unless a
+ * parameter says "host"; `stream` is a hipStream_t passed as void* (NULL = default stream).  The library
+ * never allocates, frees or synchronises; workspaces are supplied by the caller.  Every function returns
+ * 0 on success or a negative error code; gan_last_error() describes the last failure of this thread.
+ *
+ * Data layout in HBM ("halo-NHWC"): an activation is [B][Hp][Wp][C] with C a multiple of 8 (zero-filled
+ * pad channels) and an optional spatial halo already materialised by the producer (reflect or zero), so
+ * every convolution is a bounds-check-free "valid" implicit GEMM over 16-byte channel chunks.
+ */
+#ifndef MI355X_GAN_H
+#define MI355X_GAN_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { GAN_F32 = 0, GAN_BF16 = 1 };
+enum { GAN_ACT_NONE = 0, GAN_ACT_RELU = 1, GAN_ACT_LRELU = 2, GAN_ACT_TANH = 3 };
+enum { GAN_HALO_NONE = 0, GAN_HALO_ZERO = 1, GAN_HALO_REFLECT = 2 };
+
+/* A halo-NHWC activation: `ptr` addresses element [0][0][0][0] of the allocation; the logical HxW image
+ * starts at (y0,x0).  dtype: GAN_F32 or GAN_BF16. */
+typedef struct gan_view {
+  void* ptr;
+  int32_t B, Hp, Wp, C;
+  int32_t y0, x0, H, W;
+  int32_t dtype;
+  int32_t _pad;
+} gan_view;
+
+/* Generalised tap convolution (implicit GEMM on MFMA).  Row m=(b,ho,wo) of the GEMM reads, for tap t and
+ * channel c, in[((b*in_Hp + ho*in_sy + in_y0)*in_Wp + wo*in_sx + in_x0)*Cin + tapoff[t] + c] and the result
+ * for output channel n is act(sum + bias[n]) [* lrelu'(mask)] stored at
+ * out[((b*out_Hp + ho*out_sy + out_y0)*out_Wp + wo*out_sx + out_x0)*out_C + n].
+ * One descriptor covers nn.Conv2d forward, its input-gradient (flipped taps over a zero-haloed dY), the
+ * four sub-pixel phases of nn.ConvTranspose2d and their gradients. */
+typedef struct gan_conv_desc {
+  int32_t dtype;                 /* operand/out dtype */
+  int32_t B, Ho, Wo;             /* GEMM rows */
+  int32_t Cin;                   /* padded channels per tap: power of two >= 8 */
+  int32_t ntaps;                 /* padded so that ntaps*Cin is a multiple of 128 bytes of operand */
+  int32_t Nw;                    /* rows of the packed weight [Nw][ntaps][Cin]; multiple of the N tile */
+  int32_t Nst;                   /* channels stored (<= out_C, multiple of 4) */
+  const void* in;
+  int32_t in_Hp, in_Wp, in_y0, in_x0, in_sy, in_sx;
+  const int32_t* tapoff;         /* device [ntaps]: (dy*in_Wp + dx)*Cin */
+  const void* w;
+  const float* bias;             /* device fp32 [>= Nst] or NULL */
+  void* out;
+  int32_t out_Hp, out_Wp, out_C, out_y0, out_x0, out_sy, out_sx;
+  int32_t act;                   /* GAN_ACT_* applied after bias */
+  const void* mask;              /* optional LeakyReLU-derivative mask: result *= (mask>0 ? 1 : 0.2); element
+                                    ((b*mask_Hp + ho*out_sy + mask_y0)*mask_Wp + wo*out_sx + mask_x0)*out_C + n */
+  int32_t mask_Hp, mask_Wp, mask_y0, mask_x0;
+  float* stats;                  /* optional InstanceNorm partials fp32 [B][P][out_C][2], P = gan_conv_stats_parts(desc) > 0: per
+                                    (image, pixel tile, channel) sum and sum of squares of the result (bias included, before its
+                                    rounding to the output type), written with plain stores (deterministic); act must be none */
+  int32_t max_tapoff;            /* largest value in tapoff[] (needed by the range-patch kernel's span check) */
+  int32_t w_layout;              /* 0: w is [Nw][ntaps][Cin] (generic kernel); 1: fragment-major [Nw/16][ntaps*Cin/32][64][8]
+                                    for the range-patch kernel (the descriptor must satisfy gan_conv_patch_ok) */
+} gan_conv_desc;
+
+/* Weight-gradient GEMM: part[s][n][t][c] = sum over the rows m of split s of
+ * g[g_off(m) + n] * x[x_off(m) + tapoff[t] + c], with g_off/x_off as in gan_conv_desc.  nsplit slabs. */
+typedef struct gan_wgrad_desc {
+  int32_t dtype;
+  int32_t B, Ho, Wo;
+  int32_t Cx;                    /* channels of x per tap (multiple of 8) */
+  int32_t ntaps;                 /* real taps */
+  int32_t N;                     /* channels of g used (multiple of 8) */
+  int32_t nsplit;
+  const void* x;
+  int32_t x_Hp, x_Wp, x_y0, x_x0, x_sy, x_sx;
+  const int32_t* tapoff;         /* device [ntaps]: (dy*x_Wp + dx)*Cx */
+  const void* g;
+  int32_t g_Hp, g_Wp, g_C, g_y0, g_x0, g_sy, g_sx;
+  float* part;                   /* device fp32 [nsplit][N][ntaps][Cx] */
+  int32_t max_tapoff;            /* largest value in tapoff[] (range-patch variant's span check) */
+  int32_t variant;               /* 0: generic kernel, any nsplit; 1: range-patch kernel, nsplit = B * gan_wgrad_patch_splits() */
+} gan_wgrad_desc;
+
+const char* gan_last_error(void);
+int gan_version(void);
+
+/* ---- convolution family: replaces nn.Conv2d / nn.ConvTranspose2d forward+backward
+ *      (GAN_Variant1/models/generator_resnet_attn.py:33,48,113,125,146-149,160; discriminator_patchgan.py:27,38,45,51;
+ *       Basic_GAN/src/models.py:12,16,29,37,50-51,59,81,88,96,103) */
+int gan_conv_igemm(const gan_conv_desc* d, void* stream);
+/* 1 if the descriptor qualifies for the range-patch kernel (bf16, Cin % 64 == 0, Nw % 128 == 0, one tile's pixel span fits
+ * the LDS slab); pure host-side predicate used by the planner to choose the weight layout */
+int gan_conv_patch_ok(const gan_conv_desc* d);
+/* pixel tiles per image for which the descriptor's launch writes InstanceNorm partials to d->stats; 0: it cannot (then use gan_in_stats) */
+int gan_conv_stats_parts(const gan_conv_desc* d);
+int gan_conv_wgrad(const gan_wgrad_desc* d, void* stream);
+/* splits per image the range-patch weight-gradient kernel wants (0: the descriptor does not qualify: bf16, 9 taps, stride 1,
+ * Cx % 64 == 0, N % 128 == 0, one 128-pixel stage's window span fits LDS); pure host-side predicate for the planner */
+int gan_wgrad_patch_splits(const gan_wgrad_desc* d);
+/* grad[(a*I2 + b)*KK + khw[t]] (+)= sum_s part[s][n][t][c], (a,b) = swap ? (c,n) : (n,c), for n<N_real, c<C_real, khw[t]>=0 */
+int gan_wgrad_reduce(const float* part, int nsplit, int N, int ntaps, int Cx, int N_real, int C_real, int swap, int I2,
+                     int KK, const int32_t* khw, float* grad, int accumulate, void* stream);
+/* dst[n][t][c] = src[(a*I2 + b)*KK + khw[t]] (0 where n>=N_real, c>=C_real or khw[t]<0); dst dtype GAN_*.
+ * layout 0: row-major [Nw][ntaps][Cin]; layout 1: fragment-major, element (n, k=t*Cin+c) at
+ * (((n/16)*(ntaps*Cin/32) + k/32)*64 + ((k%32)/8)*16 + n%16)*8 + k%8 (one MFMA operand fragment = 1 KB contiguous) */
+int gan_pack_weight(const float* src, void* dst, int dtype, int Nw, int ntaps, int Cin, int N_real, int C_real, int swap,
+                    int I2, int KK, const int32_t* khw, int layout, void* stream);
+/* gan_pack_weight for many operand copies in one launch.  `descs` is a DEVICE array of n descriptors (fields as the arguments
+ * of gan_pack_weight); the caller assigns each a contiguous block range: first_block = running sum of nblocks (256 threads per
+ * block, any nblocks >= 1), total_blocks = their sum.  Validation of each descriptor is the caller's (same rules). */
+typedef struct gan_pack_desc {
+  const float* src; void* dst; const int32_t* khw;
+  int32_t dtype, Nw, ntaps, Cin, N_real, C_real, swap, I2, KK, layout, first_block, nblocks;
+} gan_pack_desc;
+int gan_pack_weight_batch(const gan_pack_desc* descs, int n, int total_blocks, void* stream);
+/* bias gradient: grad[n] (+)= sum over logical pixels of g[...,n], n < N_real (column sums of dY) */
+int gan_bias_grad(const gan_view* g, int N_real, float* grad, int accumulate, float* ws, void* stream);
+
+/* ---- InstanceNorm2d (+ReLU/LeakyReLU, + residual add, + halo fill): replaces nn.InstanceNorm2d, nn.ReLU,
+ *      nn.ReflectionPad2d and the residual add (generator_resnet_attn.py:25,43,56,64,71,111,114-115,126-127,150-151,158;
+ *      Basic_GAN/src/models.py:10-18,30-31,38-39,52-53,91-92,99-100).  stats = fp32 [B][C][2] (mean, rstd). */
+int gan_in_stats(const gan_view* x, float eps, float* stats, float* ws, void* stream);
+/* (mean, rstd) from the per-tile partials a convolution epilogue wrote to gan_conv_desc.stats (parts = [B][nparts][C][2]) */
+int gan_in_stats_from_parts(const float* parts, int nparts, int B, int C, int HW, float eps, float* stats, void* stream);
+/* turns whole-image sums (sum, sum of squares) into (mean, rstd) in place */
+int gan_in_finalize(float* stats, int BC, int HW, float eps, void* stream);
+int gan_in_apply(const gan_view* x, const float* stats, int act, const gan_view* residual, const gan_view* y,
+                 int halo_mode, void* stream);
+/* backward: g = (fold of `gy` over its reflect halo if fold) [+ g2], masked by act'(xhat) (relu / lrelu);
+ * dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) written to the interior of `dx` (halo untouched).
+ * ws: fp32 >= B*96*C*2 + B*C*2 floats (gan_in_stats: B*96*C*2). */
+int gan_in_bwd(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2,
+               const gan_view* dx, float* ws, void* stream);
+/* gan_in_bwd that also produces the gradient of the convolution bias in front of the norm (column sums of dx) in the same
+ * pass: bias_grad[n] (+)= sum_pixels dx[..,n], n < bias_n.  ws: fp32 >= B*96*C*2 + B*C*2 + (B*1024+32)*C floats. */
+int gan_in_bwd_bias(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2,
+                    const gan_view* dx, float* ws, float* bias_grad, int bias_n, int bias_accumulate, void* stream);
+/* out = a + fold(b): gradient of a residual block input (skip path + reflect-padded conv path) */
+int gan_fold_add(const gan_view* a, const gan_view* b, int fold, const gan_view* out, void* stream);
+/* dx = g * act'(y) (tanh: 1-y^2, lrelu: y>0?1:0.2), g optionally folded; written to the interior of dx */
+int gan_act_bwd(const gan_view* y, int act, const gan_view* g, int fold, const gan_view* g2, const gan_view* dx, void* stream);
+
+/* ---- layout boundary: NCHW fp32 (the reference's tensors) <-> halo-NHWC */
+int gan_nchw_to_view(const float* src, int C, const gan_view* dst, int halo_mode, void* stream);
+int gan_view_to_nchw(const gan_view* src, int C, float* dst, void* stream);
+int gan_view_copy(const gan_view* src, const gan_view* dst, int halo_mode, void* stream);   /* interior copy + halo fill */
+
+/* ---- DiffAugment (GAN_Variant1/training/diffaugment.py:6-60,94-106), per-sample parameters injected.
+ *      prm = device fp32 [B][12]: brightness add, saturation factor, contrast factor, tx, ty,
+ *      cut_lo_h, cut_hi_h, cut_lo_w, cut_hi_w (inclusive; lo>hi = no cutout), 3 spare.  C = real channels (3). */
+int gan_diffaug_fwd(const gan_view* x, int C, const float* prm, const gan_view* y, float* ws, void* stream);
+int gan_diffaug_bwd(const gan_view* gy, int C, const float* prm, const gan_view* gx, float* ws, void* stream);
+
+/* ---- losses.  Every loss writes its value to *loss (device fp32, overwritten) and the gradient wrt its input.
+ *      hinge: adv_hinge.py:6-62 (mode 0: mean relu(1-x), 1: mean relu(1+x), 2: -mean x), scaled by `scale`;
+ *      lsgan/bce: Basic_GAN/src/losses.py:5-22 (mode 3: mse vs target, 4: bce-with-logits vs target in {0,1});
+ *      l1: identity_l1.py:18-20 and Basic_GAN/src/losses.py:24-30 (target given as NCHW fp32). */
+int gan_patch_loss(const gan_view* logits, int mode, float target, float scale, float* loss, const gan_view* grad, void* stream);
+int gan_l1_loss(const gan_view* x, int C, const float* target_nchw, float scale, const float* dev_grad_scale, float* loss,
+                const gan_view* grad, float* ws, void* stream);   /* grad additionally * (*dev_grad_scale) if non-NULL */
+/* r1 = (1/B) sum_b sum_chw g^2 (train_cutpp.py:201) and u = scale * 2 g / B into `u` (interior) */
+int gan_r1_reduce(const gan_view* g, int C, float scale, float* loss, const gan_view* u, float* ws, void* stream);
+
+/* ---- PatchNCE (GAN_Variant1/losses/patchnce_cut.py:42-110) for one feature layer.
+ *      ids: device int32 [P] positions in [0,H*W).  ws: fp32 workspace >= gan_patchnce_ws_floats(B,P,C).
+ *      fwd: *loss += weight * mean_b CE (non-finite per-image losses count as 0).  bwd: grad rows of tgt
+ *      (scaled by weight) are ADDED into `gtgt` (duplicates in ids accumulate). */
+int64_t gan_patchnce_ws_floats(int B, int P, int C);
+int gan_patchnce_fwd(const gan_view* src, const gan_view* tgt, const int32_t* ids, int P, int C, float temperature,
+                     float weight, float* loss, float* ws, void* stream);
+int gan_patchnce_bwd(const gan_view* tgt, const int32_t* ids, int P, int C, float temperature, float weight,
+                     const gan_view* gtgt, float* ws, void* stream);
+
+/* ---- fused clip_grad_norm_ + Adam + EMA (amp_utils.py:29-41, sched_optim.py:5-27, io_ckpt.py:23-29) over a
+ *      tensor list.  The table is a device array of gan_adam_tensor; tensors with g == NULL are skipped. */
+typedef struct gan_adam_tensor {
+  float* p; const float* g; float* m; float* v; float* ema;   /* ema may be NULL */
+  int64_t numel;
+  int32_t* step;                                               /* device per-tensor step counter (incremented) */
+  int64_t _pad;
+} gan_adam_tensor;
+/* norm_out: device fp32 [2] = (total L2 norm before clipping, clip coefficient).  max_norm <= 0: no clipping.
+ * grad_scale multiplies every gradient first (1/world_size after a sum all-reduce). */
+int gan_adam_step(const gan_adam_tensor* table, int ntensors, const int32_t* chunk_tensor, const int64_t* chunk_off,
+                  int nchunks, float lr, float beta1, float beta2, float eps, float max_norm, float grad_scale,
+                  float ema_decay, float* norm_out, float* ws, void* stream);
+
+/* small helpers */
+int gan_fill_f32(float* p, int64_t n, float v, void* stream);
+int gan_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream);   /* y += a*x */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,229 @@
+"""Generates tests/golden/*.npz by importing the reference itself (build container only).
+
+Run from the repo root:  python -m oracle.make_golden
+The reference lives at /root/reference (read-only, absent on the GPU box); only *data* (inputs and
+expected outputs) is written to tests/golden/.  `torchvision` is absent in the image and the reference's
+train_cutpp imports it at module scope without using it on the step path, so empty stand-in modules are
+registered in sys.modules for that import.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _import_reference():
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REF, "Basic_GAN"))
+    for m in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    from GAN_Variant1.training import train_cutpp  # noqa
+    return train_cutpp
+
+
+def _np(d):
+    return {k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()}
+
+
+def _cfg(tc):
+    import yaml
+
+    cfg = yaml.safe_load(open(os.path.join(REF, "GAN_Variant1/configs/train_gan_cutpp.yaml")))
+    cfg["amp"] = False
+    return cfg
+
+
+def _inputs(B, S, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    photos = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    monets = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    return photos, monets
+
+
+def gen_models(tc):
+    """Model-level vectors: init KAT (first values of every tensor), G / D / feature outputs at 64^2 and 32^2."""
+    from GAN_Variant1.utils.seed_dist import set_seed
+
+    cfg = _cfg(tc)
+    set_seed(42)
+    G, D = tc.build_models(cfg, "cpu")
+    out = {}
+    for name, net in (("G", G), ("D", D)):
+        for k, v in net.state_dict().items():
+            out[f"init.{name}.{k}"] = v.reshape(-1)[:16].clone()
+            out[f"initsum.{name}.{k}"] = v.double().sum().float()
+    x, _ = _inputs(2, 64)
+    with torch.no_grad():
+        out["x64"] = x
+        out["G64"] = G(x)
+        feats = G.get_feature_layers(x, [0, 4, 8, 12, 16])
+        out["nfeats"] = torch.tensor(len(feats))
+        for i, f in enumerate(feats):
+            out[f"feat{i}.shape"] = torch.tensor(f.shape)
+            out[f"feat{i}.slice"] = f[:, :8, :4, :4].clone()
+            out[f"feat{i}.sum"] = f.double().sum().float()
+        out["D64"] = D(x)[0]
+        out["D64_of_G"] = D(G(x))[0]
+    np.savez_compressed(os.path.join(OUT, "cut_models.npz"), **_np(out))
+
+
+def gen_losses(tc):
+    from GAN_Variant1.losses.adv_hinge import discriminator_hinge_loss, generator_hinge_loss
+    from GAN_Variant1.losses.patchnce_cut import PatchNCELoss
+    from GAN_Variant1.training import diffaugment as da
+
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    # PatchNCE: one layer, ids recorded by re-seeding the global generator the reference draws from.
+    for tag, (B, C, H) in {"a": (2, 64, 16), "b": (3, 128, 8), "c": (2, 32, 12)}.items():
+        src = torch.randn(B, C, H, H, generator=g)
+        tgt = (src + 0.5 * torch.randn(B, C, H, H, generator=g)).requires_grad_(True)
+        torch.manual_seed(100 + B)
+        ids = torch.randint(0, H * H, (min(256, H * H),))
+        torch.manual_seed(100 + B)
+        loss = PatchNCELoss(0.07, 256)._compute_nce_loss(src, tgt)
+        (gt,) = torch.autograd.grad(loss, tgt)
+        out.update({f"nce.{tag}.src": src, f"nce.{tag}.tgt": tgt.detach(), f"nce.{tag}.ids": ids,
+                    f"nce.{tag}.loss": loss.detach(), f"nce.{tag}.gtgt": gt})
+    # hinge
+    r = torch.randn(2, 1, 6, 6, generator=g).requires_grad_(True)
+    f = torch.randn(2, 1, 6, 6, generator=g).requires_grad_(True)
+    dl = discriminator_hinge_loss([r], [f])
+    gr, gf = torch.autograd.grad(dl, [r, f])
+    out.update({"hinge.real": r.detach(), "hinge.fake": f.detach(), "hinge.d": dl.detach(), "hinge.d.greal": gr,
+                "hinge.d.gfake": gf, "hinge.g": generator_hinge_loss([f]).detach()})
+    # DiffAugment with the global generator re-seeded: the oracle's sampler must draw the same numbers.
+    x = (torch.rand(3, 3, 32, 32, generator=g) * 2 - 1).requires_grad_(True)
+    torch.manual_seed(555)
+    y = da.DiffAugment(["color", "translation", "cutout"])(x)
+    w = torch.randn(y.shape, generator=g)
+    (gx,) = torch.autograd.grad((y * w).sum(), x)
+    out.update({"aug.x": x.detach(), "aug.y": y.detach(), "aug.w": w, "aug.gx": gx, "aug.seed": torch.tensor(555)})
+    np.savez_compressed(os.path.join(OUT, "cut_losses.npz"), **_np(out))
+
+
+def gen_optim(tc):
+    from GAN_Variant1.training.sched_optim import get_optimizer
+    from GAN_Variant1.utils.amp_utils import AMPContext
+    from GAN_Variant1.utils.io_ckpt import EMA
+
+    g = torch.Generator().manual_seed(3)
+    net = torch.nn.ParameterDict({"a": torch.nn.Parameter(torch.randn(5, 7, generator=g)),
+                                  "b": torch.nn.Parameter(torch.randn(11, generator=g)),
+                                  "z": torch.nn.Parameter(torch.randn(4, generator=g))})
+    opt = get_optimizer(net, {"lr": 2e-4, "betas": [0.5, 0.999], "weight_decay": 0.0})
+    amp = AMPContext(enabled=False)
+    ema = EMA(net, 0.999)
+    out = {f"p0.{k}": v.detach().clone() for k, v in net.items()}
+    for s in range(3):
+        opt.zero_grad()
+        grads = {"a": torch.randn(5, 7, generator=g) * (30.0 if s == 1 else 1.0), "b": torch.randn(11, generator=g),
+                 "z": torch.zeros(4)}
+        for k, v in net.items():
+            v.grad = grads[k].clone()
+            out[f"g{s}.{k}"] = grads[k]
+        amp.step_optimizer(opt, max_grad_norm=10.0)
+        ema.update()
+        for k, v in net.items():
+            out[f"p{s+1}.{k}"] = v.detach().clone()
+            out[f"ema{s+1}.{k}"] = ema.shadow[k].clone()
+    np.savez_compressed(os.path.join(OUT, "cut_optim.npz"), **_np(out))
+
+
+def gen_steps(tc):
+    """Real reference train_step, B=2 @64^2 (and 32^2), steps 0-1, amp off; DiffAugment off and on."""
+    from GAN_Variant1.training.diffaugment import DiffAugment
+    from GAN_Variant1.training.sched_optim import get_optimizer
+    from GAN_Variant1.utils.amp_utils import AMPContext
+    from GAN_Variant1.utils.io_ckpt import EMA
+    from GAN_Variant1.utils.seed_dist import set_seed
+
+    cfg = _cfg(tc)
+    out = {}
+    for tag, S, use_aug in (("noaug64", 64, False), ("aug64", 64, True), ("aug32", 32, True)):
+        torch.set_num_threads(1)
+        set_seed(42)
+        G, D = tc.build_models(cfg, "cpu")
+        opt_G, opt_D = get_optimizer(G, cfg["optim"]["G"]), get_optimizer(D, cfg["optim"]["D"])
+        ema, amp = EMA(G, cfg["ema"]["decay"]), AMPContext(enabled=False)
+        aug = DiffAugment(cfg["diffaugment"]["policy"]) if use_aug else None
+        photos, monets = _inputs(2, S)
+        out[f"{tag}.photos"], out[f"{tag}.monets"] = photos, monets
+        for step in range(2):
+            torch.manual_seed(9000 + step)  # the oracle re-seeds identically before drawing the step's randomness
+            losses = tc.train_step(step, photos.clone(), monets.clone(), G, D, opt_G, opt_D, ema, amp, aug, cfg, "cpu")
+            for k, v in losses.items():
+                out[f"{tag}.step{step}.{k}"] = torch.tensor(v, dtype=torch.float64)
+            if step == 0:
+                with torch.no_grad():
+                    out[f"{tag}.G_after_step0"] = G(photos)
+                    out[f"{tag}.Dreal_after_step0"] = D(photos)[0]
+        torch.set_num_threads(8)
+    np.savez_compressed(os.path.join(OUT, "cut_steps.npz"), **_np(out))
+
+
+def gen_basic():
+    from src.losses import GANLoss, cycle_loss, identity_loss  # Basic_GAN/src
+    from src.models import NLayerDiscriminator, ResnetGenerator
+    from torch.optim import Adam
+
+    torch.set_num_threads(1)
+    torch.manual_seed(0)
+    G_ab, G_ba = ResnetGenerator(ngf=64, n_blocks=9), ResnetGenerator(ngf=64, n_blocks=9)
+    D_a, D_b = NLayerDiscriminator(ndf=64), NLayerDiscriminator(ndf=64)
+    out = {}
+    for name, net in (("G_ab", G_ab), ("G_ba", G_ba), ("D_a", D_a), ("D_b", D_b)):
+        for k, v in net.state_dict().items():
+            out[f"init.{name}.{k}"] = v.reshape(-1)[:16].clone()
+    a, b = _inputs(2, 64, seed=77)
+    out["real_a"], out["real_b"] = a, b
+    with torch.no_grad():
+        out["G_ab(a)"] = G_ab(a)
+        out["D_a(a)"] = D_a(a)
+    pred = torch.randn(2, 1, 6, 6, generator=torch.Generator().manual_seed(5))
+    out["gl.pred"] = pred
+    for mode in ("lsgan", "bce"):
+        out[f"gl.{mode}.real"] = GANLoss(mode)(pred, True)
+        out[f"gl.{mode}.fake"] = GANLoss(mode)(pred, False)
+    # restated inner loop (train.py:66-122) with the imported classes, amp off
+    gan = GANLoss("lsgan")
+    oG = Adam(list(G_ab.parameters()) + list(G_ba.parameters()), lr=2e-4, betas=(0.5, 0.999))
+    oA = Adam(D_a.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    oB = Adam(D_b.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    for it in range(2):
+        oG.zero_grad(set_to_none=True)
+        fake_B = G_ab(a); rec_A = G_ba(fake_B); fake_A = G_ba(b); rec_B = G_ab(fake_A)
+        idt_B = G_ab(b); idt_A = G_ba(a)
+        loss_G = (gan(D_b(fake_B), True) + gan(D_a(fake_A), True) + cycle_loss(rec_A, a, 10.0) + cycle_loss(rec_B, b, 10.0)
+                  + identity_loss(idt_A, a, 0.5) + identity_loss(idt_B, b, 0.5))
+        loss_G.backward(); oG.step()
+        oA.zero_grad(set_to_none=True)
+        loss_A = 0.5 * (gan(D_a(a), True) + gan(D_a(fake_A.detach()), False)); loss_A.backward(); oA.step()
+        oB.zero_grad(set_to_none=True)
+        loss_B = 0.5 * (gan(D_b(b), True) + gan(D_b(fake_B.detach()), False)); loss_B.backward(); oB.step()
+        out[f"it{it}.loss_G"], out[f"it{it}.loss_D_A"], out[f"it{it}.loss_D_B"] = loss_G.detach(), loss_A.detach(), loss_B.detach()
+    torch.set_num_threads(8)
+    np.savez_compressed(os.path.join(OUT, "basic.npz"), **_np(out))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    tc = _import_reference()
+    gen_models(tc)
+    gen_losses(tc)
+    gen_optim(tc)
+    gen_steps(tc)
+    gen_basic()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,152 @@
+"""Host logic on CPU: the engine (tap tables, halos, sub-pixel phases, program order, optimiser tables) driven through
+the emulator (tests/emulator.py) must reproduce the oracle.  No GPU, no HIP kernel launches."""
+import numpy as np
+import pytest
+import torch
+
+from gan_variant_research_amd import BF16, F32
+from gan_variant_research_amd import cut as C
+from gan_variant_research_amd.runtime import Ctx
+from oracle import cut_ref
+from tests import cases
+from tests.emulator import EmuOps
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("geom", cases.GEOMS[:8])
+def test_conv_geometry(geom, dtype):
+    cases.run_conv_geometry(Ctx(EmuOps(), "cpu", dtype), geom, dtype)
+
+
+@pytest.mark.parametrize("geom", [cases.GEOMS[8], cases.GEOMS[10], cases.GEOMS[13]])
+def test_conv_geometry_fragment_major(geom):
+    """Full-width bf16 layers take the range-patch kernel: fragment-major weight copies, checked through the emulator."""
+    ctx = Ctx(EmuOps(), "cpu", BF16)
+    seen = []
+    orig = ctx.ops.conv_igemm
+    ctx.ops.conv_igemm = lambda c: (seen.append(c.w_frag), orig(c))[1]
+    cases.run_conv_geometry(ctx, geom, BF16)
+    assert any(seen), "no call qualified for the range-patch kernel"
+
+
+def test_module_state_dict_keys_and_init():
+    cut_ref.set_seed(42)
+    gp, dp = cut_ref.init_generator(), cut_ref.init_discriminator()
+    C.set_seed(42)
+    gen, disc = C.build_models(cases.small_config(), "cpu")
+    gs, ds = gen.state_dict(), disc.state_dict()
+    assert list(gs) == list(gp) and list(ds) == list(dp)
+    for k in gp:
+        assert torch.equal(gs[k], gp[k]), k
+    for k in dp:
+        assert torch.equal(ds[k], dp[k]), k
+
+
+@pytest.mark.parametrize("use_aug", [True, False])
+def test_cut_train_step_matches_oracle(use_aug):
+    torch.set_num_threads(4)
+    cases.run_cut_steps("cpu", EmuOps(), use_aug)
+
+
+def test_basic_gan_iterations_match_oracle():
+    torch.set_num_threads(4)
+    cases.run_basic_iterations("cpu", EmuOps())
+
+
+def test_cut_trainer_checkpoint_round_trip(tmp_path):
+    """CutTrainer.save_checkpoint / load_checkpoint (utils/io_ckpt.py:56-118 layout): a resumed trainer continues bit-identically,
+    and the file's optimiser state loads into the reference's torch.optim.Adam."""
+    import copy
+    from gan_variant_research_amd import cut as C
+    cfg = cases.small_config()
+    cfg["diffaugment"]["enable"] = True
+    B, S = 2, 32
+
+    def make():
+        C.set_seed(42)
+        gen, disc = C.build_models(cfg, "cpu")
+        return C.CutTrainer(gen, disc, cfg, B, S, device="cpu", amp=False, ops=EmuOps())
+    g = torch.Generator().manual_seed(5)
+    photos, monets = torch.rand(B, 3, S, S, generator=g) * 2 - 1, torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    a = make()
+    rnds = []
+    for step in range(3):
+        torch.manual_seed(100 + step)
+        rnds.append(a.sample_randomness())
+    a.train_step(0, photos, monets, rnds[0])
+    a.train_step(1, photos, monets, rnds[1])
+    path = str(tmp_path / "run" / "ckpt_2.pt")
+    a.save_checkpoint(path, 2, {"d_loss": 0.5})
+    raw = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(raw) == {"step", "generator", "discriminator", "opt_G", "opt_D", "metrics", "config", "ema_G", "scaler"} and raw["step"] == 2
+    assert list(raw["generator"])[:2] == ["initial.1.weight", "initial.1.bias"] and "discriminators.0.model.8.bias" in raw["discriminator"]
+    assert float(raw["opt_G"]["state"][0]["step"]) == 2.0 and float(raw["opt_D"]["state"][0]["step"]) == 3.0   # D: two steps + R1 at step 0
+    # the reference's optimiser accepts the state
+    ref_gen = copy.deepcopy(a.generator)
+    ref_opt = torch.optim.Adam(ref_gen.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    ref_opt.load_state_dict(raw["opt_G"])
+    assert torch.equal(ref_opt.state[list(ref_gen.parameters())[0]]["exp_avg"], raw["opt_G"]["state"][0]["exp_avg"])
+    # resume in a fresh trainer and continue: identical to the uninterrupted run
+    want = a.train_step(2, photos, monets, rnds[2])
+    b = make()
+    assert b.load_checkpoint(path)["step"] == 2
+    got = b.train_step(2, photos, monets, rnds[2])
+    assert got == want
+    for k, v in a.opt_G.params.items():
+        assert torch.equal(v, b.opt_G.params[k]), k
+    for k, v in a.ema_state_dict()["shadow"].items():
+        assert torch.equal(v, b.ema_state_dict()["shadow"][k]), k
+
+
+def test_lagged_loss_readback_delivers_every_step():
+    """train_step(sync="lag") returns the previous step's dict; the values equal the synchronous ones."""
+    cfg = cases.small_config()
+    B, S = 2, 32
+
+    def make():
+        C.set_seed(42)
+        gen, disc = C.build_models(cfg, "cpu")
+        return C.CutTrainer(gen, disc, cfg, B, S, device="cpu", amp=False, ops=EmuOps())
+    g = torch.Generator().manual_seed(5)
+    photos, monets = torch.rand(B, 3, S, S, generator=g) * 2 - 1, torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    a, b = make(), make()
+    rnds = []
+    for step in range(3):
+        torch.manual_seed(100 + step)
+        rnds.append(a.sample_randomness())
+    want = [a.train_step(s, photos, monets, rnds[s]) for s in range(3)]
+    got = [b.train_step(s, photos, monets, rnds[s], sync="lag") for s in range(3)]
+    assert got[0] is None and got[1] == want[0] and got[2] == want[1]
+    assert b.flush_losses() == want[2] and b.flush_losses() is None
+
+
+def test_merged_identity_pass_equals_separate_passes_and_mode_switch():
+    """G(photos) and G(monets) as one 2B pass (identity warm-up) == three separate passes; when the identity weight reaches zero the
+    trainer switches to the photos-only programs (train_cutpp.py:224-228, 293-295)."""
+    B, S = 2, 32
+    g = torch.Generator().manual_seed(5)
+    photos, monets = torch.rand(B, 3, S, S, generator=g) * 2 - 1, torch.rand(B, 3, S, S, generator=g) * 2 - 1
+
+    def make(merge):
+        cfg = cases.small_config()
+        cfg["diffaugment"]["enable"] = True
+        cfg["warmup_steps"] = 2                      # identity weight: 0.1 at step 0, 0.05 at step 1, 0 from step 2 on
+        cfg["merge_identity_pass"] = merge
+        C.set_seed(42)
+        gen, disc = C.build_models(cfg, "cpu")
+        return C.CutTrainer(gen, disc, cfg, B, S, device="cpu", amp=False, ops=EmuOps())
+    a, b = make(True), make(False)
+    assert a.mode_merged and not b.mode_merged and a.p1.B == 2 * B and b.p1.B == B
+    for step in range(4):
+        torch.manual_seed(100 + step)
+        rnd = a.sample_randomness()
+        la, lb = a.train_step(step, photos, monets, rnd), b.train_step(step, photos, monets, rnd)
+        assert a.mode_merged == (step < 2)
+        assert la["identity_weight"] == lb["identity_weight"] and (la["identity"] == 0.0) == (step >= 2)
+        for k in la:
+            # from step 1 on, parameters whose gradient is rounding noise have moved by +-lr differently: same
+            # tolerances as the oracle comparison of tests/cases.py
+            np.testing.assert_allclose(la[k], lb[k], rtol=2e-5 if step == 0 else 2e-3, atol=1e-3 if (k == "g_adv" and step) else 2e-5,
+                                       err_msg=f"step {step} {k}")
+    worst = max(float((a.opt_G.params[k] - v).abs().max()) for k, v in b.opt_G.params.items())
+    assert worst < 1.7e-3, worst     # four sign-like Adam steps of lr 2e-4: +lr in one run, -lr in the other, on weights whose gradient is rounding noise

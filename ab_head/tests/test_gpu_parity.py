@@ -1,0 +1,344 @@
+"""Parity tests proper (MI355X, through the C ABI): every HIP kernel against its CPU statement / the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from gan_variant_research_amd import BF16, F32
+from gan_variant_research_amd.runtime import Ctx, HipOps, View
+from tests import cases
+from tests.emulator import EmuOps
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def hip_ctx(dtype):
+    return Ctx(HipOps(torch.device(DEV)), DEV, dtype)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("geom", cases.GEOMS)
+def test_conv_geometry_hip(geom, dtype):
+    cases.run_conv_geometry(hip_ctx(dtype), geom, dtype, B=3)
+
+
+@pytest.mark.parametrize("geom", [g for g in cases.GEOMS if max(g[0], g[1]) >= 64])
+def test_conv_geometry_hip_tile288(geom, monkeypatch):
+    """The 288-row tile of the range-patch kernel is only chosen on large launches (tile-count quantisation); force it."""
+    monkeypatch.setenv("GAN_PATCH_BM", "288")
+    cases.run_conv_geometry(hip_ctx(BF16), geom, BF16, B=3)
+
+
+# ---------------------------------------------------------------------------------------------- op twins
+class Twin:
+    """The same buffers on CPU (emulator) and GPU (HIP); ops are built on both and every buffer is compared afterwards."""
+
+    def __init__(self, dtype, seed=0):
+        self.dtype = dtype
+        self.c, self.g = Ctx(EmuOps(), "cpu", dtype), hip_ctx(dtype)
+        self.gen = torch.Generator().manual_seed(seed)
+        self.views, self.tensors = [], []
+
+    def view(self, B, H, W, C, halo, rand=True, scale=1.0, zero_halo=False):
+        vc = self.c.view(B, H, W, C, halo)
+        if rand:
+            data = torch.randn(vc.t.shape, generator=self.gen) * scale
+            vc.t.copy_(data.to(vc.t.dtype))
+            if zero_halo and halo:
+                interior = vc.nhwc().clone()
+                vc.t.zero_()
+                vc.nhwc().copy_(interior)
+        vg = self.g.view(B, H, W, C, halo)
+        vg.t.copy_(vc.t)
+        self.views.append((vc, vg))
+        return vc, vg
+
+    def f32(self, data):
+        tc = data.clone().float()
+        tg = tc.to(DEV)
+        self.tensors.append((tc, tg))
+        return tc, tg
+
+    def i32(self, data):
+        tc = torch.as_tensor(data, dtype=torch.int32)
+        return tc, tc.to(DEV)
+
+    def run(self, cpu_ops, gpu_ops):
+        for o in cpu_ops if isinstance(cpu_ops, (list, tuple)) else [cpu_ops]:
+            o()
+        for o in gpu_ops if isinstance(gpu_ops, (list, tuple)) else [gpu_ops]:
+            o()
+        torch.cuda.synchronize()
+
+    def check(self, rtol, atol):
+        for i, (vc, vg) in enumerate(self.views):
+            np.testing.assert_allclose(vg.t.float().cpu().numpy(), vc.t.float().numpy(), rtol=rtol, atol=atol, err_msg=f"view {i}")
+        for i, (tc, tg) in enumerate(self.tensors):
+            np.testing.assert_allclose(tg.cpu().numpy(), tc.numpy(), rtol=rtol, atol=atol, err_msg=f"tensor {i}")
+
+
+TOL = {F32: (2e-5, 2e-5), BF16: (2e-2, 2e-2)}
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 1), (3, 12, 20, 256, 1), (2, 32, 32, 8, 3), (2, 9, 9, 512, 1)])
+def test_instance_norm_twins(shape, dtype):
+    B, H, W, C, halo = shape
+    for act, res, mode in ((1, False, 2), (0, True, 2), (2, False, 1)):
+        tw = Twin(dtype, seed=act)
+        xc, xg = tw.view(B, H, W, C, 0)
+        rc, rg = tw.view(B, H, W, C, halo) if res else (None, None)
+        yc, yg = tw.view(B, H, W, C, halo, rand=False)
+        sc, sg = tw.f32(torch.zeros(B * C * 2))
+        wc, wg = tw.f32(torch.zeros(B * 96 * C * 2 + B * C * 2))
+        tw.run([tw.c.ops.in_stats(xc, 1e-5, sc, wc), tw.c.ops.in_apply(xc, sc, act, rc, yc, mode)],
+               [tw.g.ops.in_stats(xg, 1e-5, sg, wg), tw.g.ops.in_apply(xg, sg, act, rg, yg, mode)])
+        tw.tensors.pop()  # workspace contents are a kernel detail
+        tw.check(*TOL[dtype])
+        # backward: folded padded-domain gradient + second addend
+        gc, gg = tw.view(B, H, W, C, halo, scale=0.5)
+        g2c, g2g = tw.view(B, H, W, C, 0, scale=0.5)
+        dc, dg = tw.view(B, H, W, C, 2, rand=False)
+        fold = halo if H >= 2 * halo + 2 else 0
+        tw.run(tw.c.ops.in_bwd(xc, sc, act, gc, bool(fold), g2c, dc, wc), tw.g.ops.in_bwd(xg, sg, act, gg, bool(fold), g2g, dg, wg))
+        tw.check(TOL[dtype][0] * 5, TOL[dtype][1] * 5)
+        # the same backward with the fused bias gradient, twice (the second call accumulates)
+        nb = max(1, C - 3)
+        bc, bg = tw.f32(torch.zeros(nb))
+        w2c, w2g = tw.f32(torch.zeros(B * 96 * C * 2 + B * C * 2 + (B * 1024 + 32) * C))
+        tw.tensors.pop()
+        for acc in (False, True):
+            tw.run(tw.c.ops.in_bwd_bias(xc, sc, act, gc, bool(fold), g2c, dc, w2c, bc, nb, acc),
+                   tw.g.ops.in_bwd_bias(xg, sg, act, gg, bool(fold), g2g, dg, w2g, bg, nb, acc))
+        # column sums of dx are zero in exact arithmetic (non-affine norm): what is compared is rounding noise of B*H*W addends
+        np.testing.assert_allclose(bg.cpu().numpy(), bc.numpy(), rtol=TOL[dtype][0] * 5, atol=TOL[dtype][1] * 5 * (B * H * W) ** 0.5)
+        tw.tensors.pop()   # bias compared above with a magnitude-aware tolerance
+        tw.check(TOL[dtype][0] * 5, TOL[dtype][1] * 5)
+        oc, og = tw.view(B, H, W, C, 0, rand=False)
+        tw.run(tw.c.ops.fold_add(g2c, gc, bool(fold), oc), tw.g.ops.fold_add(g2g, gg, bool(fold), og))
+        tw.run(tw.c.ops.act_bwd(yc, 3, gc, bool(fold), g2c, dc), tw.g.ops.act_bwd(yg, 3, gg, bool(fold), g2g, dg))
+        tw.check(TOL[dtype][0] * 5, TOL[dtype][1] * 5)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_layout_and_losses_twins(dtype):
+    B, S = 3, 24
+    tw = Twin(dtype)
+    img_c, img_g = tw.f32(torch.rand(B, 3, S, S, generator=tw.gen) * 2 - 1)
+    for halo, mode in ((3, 2), (1, 1)):
+        vc, vg = tw.view(B, S, S, 8, halo, rand=False)
+        tw.run(tw.c.ops.nchw_to_view(img_c, 3, vc, mode), tw.g.ops.nchw_to_view(img_g, 3, vg, mode))
+        wc, wg = tw.view(B, S, S, 8, halo, rand=False)
+        tw.run(tw.c.ops.view_copy(vc, wc, mode), tw.g.ops.view_copy(vg, wg, mode))
+    oc, og = tw.f32(torch.zeros(B, 3, S, S))
+    tw.run(tw.c.ops.view_to_nchw(vc, 3, oc), tw.g.ops.view_to_nchw(vg, 3, og))
+    # DiffAugment
+    from gan_variant_research_amd.cut import DiffAugment
+    aug = DiffAugment(["color", "translation", "cutout"])
+    prm = DiffAugment.to_params(aug.sample(B, S, S, tw.gen), B, S, S).reshape(-1)
+    pc, pg = tw.f32(prm)
+    xc, xg = tw.view(B, S, S, 8, 0)
+    xc.nhwc()[..., 3:] = 0; xg.t.copy_(xc.t)
+    yc, yg = tw.view(B, S, S, 8, 1, rand=False)
+    wsc, wsg = torch.zeros(64), torch.zeros(64, device=DEV)
+    tw.run(tw.c.ops.diffaug_fwd(xc, 3, pc, yc, wsc), tw.g.ops.diffaug_fwd(xg, 3, pg, yg, wsg))
+    gyc, gyg = tw.view(B, S, S, 8, 0)
+    gxc, gxg = tw.view(B, S, S, 8, 0, rand=False)
+    tw.run(tw.c.ops.diffaug_bwd(gyc, 3, pc, gxc, wsc), tw.g.ops.diffaug_bwd(gyg, 3, pg, gxg, wsg))
+    # patch losses on a logits view, all modes
+    lc, lg = tw.view(B, 6, 6, 8, 0)
+    for mode, tgt in ((0, 0.0), (1, 0.0), (2, 0.0), (3, 1.0), (4, 1.0), (4, 0.0)):
+        sc, sg = tw.f32(torch.zeros(1))
+        gc, gg = tw.view(B, 6, 6, 8, 2, rand=False)
+        tw.run(tw.c.ops.patch_loss(lc, mode, tgt, 0.5, sc, gc), tw.g.ops.patch_loss(lg, mode, tgt, 0.5, sg, gg))
+    # L1 and R1
+    sc, sg = tw.f32(torch.zeros(1)); dsc, dsg = tw.f32(torch.tensor([0.1]))
+    gc, gg = tw.view(B, S, S, 8, 0, rand=False)
+    w1c, w1g = torch.zeros(1024), torch.zeros(1024, device=DEV)
+    tw.run(tw.c.ops.l1_loss(xc, 3, img_c, 1.0, dsc, sc, gc, w1c), tw.g.ops.l1_loss(xg, 3, img_g, 1.0, dsg, sg, gg, w1g))
+    sc, sg = tw.f32(torch.zeros(1))
+    uc, ug = tw.view(B, S, S, 8, 1, rand=False)
+    tw.run(tw.c.ops.r1_reduce(xc, 3, 160.0, sc, uc, w1c), tw.g.ops.r1_reduce(xg, 3, 160.0, sg, ug, w1g))
+    tw.check(*([1e-4, 1e-5] if dtype == F32 else [2e-2, 2e-2]))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 1, 256), (3, 8, 8, 256, 1, 64), (2, 12, 12, 128, 0, 144),   # MFMA tiling
+                                   (2, 12, 12, 32, 0, 100), (2, 8, 8, 512, 1, 48)])                            # scalar-FMA fallback
+def test_patchnce_twins(shape, dtype):
+    B, H, W, C, halo, P = shape
+    tw = Twin(dtype, seed=5)
+    sc, sg = tw.view(B, H, W, C, halo)
+    tc, tg = tw.view(B, H, W, C, halo)
+    tc.t.copy_((sc.t.float() + 0.5 * tc.t.float()).to(tc.t.dtype)); tg.t.copy_(tc.t)
+    ids = torch.randint(0, H * W, (P,), generator=tw.gen)
+    ids[1] = ids[0]; ids[-1] = ids[0]          # duplicates must accumulate
+    ic, ig = tw.i32(ids)
+    lc, lg = tw.f32(torch.zeros(1))
+    gc, gg = tw.view(B, H, W, C, halo, scale=0.01)
+    n = tw.c.ops.patchnce_ws_floats(B, P, C)
+    wc, wg = torch.zeros(n), torch.zeros(n, device=DEV)
+    tw.run([tw.c.ops.patchnce_fwd(sc, tc, ic, P, C, 0.07, 0.25, lc, wc), tw.c.ops.patchnce_bwd(tc, ic, P, C, 0.07, 0.25, gc, wc)],
+           [tw.g.ops.patchnce_fwd(sg, tg, ig, P, C, 0.07, 0.25, lg, wg), tw.g.ops.patchnce_bwd(tg, ig, P, C, 0.07, 0.25, gg, wg)])
+    tw.check(*([2e-4, 2e-6] if dtype == F32 else [2e-2, 2e-3]))
+
+
+def test_adam_twins(golden):
+    """Fused clip+Adam+EMA against the golden vectors of the reference's AMPContext.step_optimizer + EMA.update."""
+    from gan_variant_research_amd.cut import FusedAdam
+    g = golden("cut_optim.npz")
+    ctx = hip_ctx(F32)
+    names = ["a", "b", "z"]
+    init = {k: torch.from_numpy(g[f"p0.{k}"]).to(DEV) for k in names}
+    opt = FusedAdam(ctx, names, [init[k].shape for k in names], init, ema_decay=0.999)
+    step = opt.step_op(10.0)
+    for s in range(3):
+        for k in names:
+            opt.grads[k].copy_(torch.from_numpy(g[f"g{s}.{k}"]))
+        step()
+        torch.cuda.synchronize()
+        for k in names:
+            np.testing.assert_allclose(opt.params[k].cpu().numpy(), g[f"p{s+1}.{k}"], rtol=2e-6, atol=2e-7)
+            np.testing.assert_allclose(opt.shadow[k].cpu().numpy(), g[f"ema{s+1}.{k}"], rtol=2e-6, atol=2e-7)
+    assert opt.steps.tolist() == [3, 3, 3]
+    skip = opt.step_op(10.0, skip=["z"])
+    skip(); torch.cuda.synchronize()
+    assert opt.steps.tolist() == [4, 4, 3]
+
+
+# ---------------------------------------------------------------------------------------------- whole step
+@pytest.mark.parametrize("use_aug", [True, False])
+def test_cut_train_step_fp32_vs_oracle(use_aug):
+    """fp32 (parity) mode: losses within 1e-3 relative of the PyTorch-CPU oracle at steps 0 and 1 (north_star tolerance)."""
+    tr, img, ref_img = cases.run_cut_steps(DEV, HipOps(torch.device(DEV)), use_aug, amp=False, S=64, B=2, tol0=1e-3, tol1=2e-3, atol1=5e-4)
+    np.testing.assert_allclose(img.numpy(), ref_img.numpy(), rtol=1e-3, atol=1e-3)
+
+
+def test_cut_train_step_bf16_vs_oracle():
+    """bf16 throughput mode (fp32 accumulation): same step, tolerance widened to bf16's 8-bit mantissa."""
+    tr, img, ref_img = cases.run_cut_steps(DEV, HipOps(torch.device(DEV)), True, amp=True, S=64, B=2, nsteps=1, tol0=4e-2, ptol=4.5e-4)
+    np.testing.assert_allclose(img.numpy(), ref_img.numpy(), rtol=5e-2, atol=5e-2)
+
+
+def test_generator_module_forward_and_features(golden):
+    """ResNetGenerator.forward / get_feature_layers on HIP vs the golden outputs of the reference modules."""
+    from gan_variant_research_amd import cut as C
+    g = golden("cut_models.npz")
+    C.set_seed(42)
+    gen, disc = C.build_models(cases.small_config(), DEV)
+    x = torch.from_numpy(g["x64"]).to(DEV)
+    assert gen(x).requires_grad                     # the modules are differentiable nn.Modules now (autograd.py)
+    with torch.no_grad():
+        np.testing.assert_allclose(gen(x).cpu().numpy(), g["G64"], rtol=1e-3, atol=1e-3)
+        feats = gen.get_feature_layers(x, [0, 4, 8, 12, 16])
+    assert len(feats) == 4
+    for i, f in enumerate(feats):
+        assert list(f.shape) == list(g[f"feat{i}.shape"])
+        np.testing.assert_allclose(f[:, :8, :4, :4].cpu().numpy(), g[f"feat{i}.slice"], rtol=1e-3, atol=1e-3)
+
+
+def test_basic_gan_iterations_fp32_vs_oracle():
+    """Basic_GAN CycleGAN inner loop (Basic_GAN/src/train.py:66-122), fp32 parity mode, 64x64, two iterations."""
+    cases.run_basic_iterations(DEV, HipOps(torch.device(DEV)), amp=False, S=64, B=2, tol0=1e-3, tol1=2e-3)
+
+
+def test_basic_gan_iterations_bf16_vs_oracle():
+    cases.run_basic_iterations(DEV, HipOps(torch.device(DEV)), amp=True, S=64, B=2, niter=1, tol0=4e-2)
+
+
+# ---------------------------------------------------------------------------------------------- drop-in nn.Module / loss / optimiser API
+def test_autograd_bridge_hip():
+    """G(x), get_feature_layers, D(x), r1_regularization as differentiable nn.Module calls on the HIP kernels vs the oracle under autograd."""
+    from tests.test_autograd_bridge import bridge_cases
+    bridge_cases(DEV, 5e-4)
+
+
+def test_loss_callables_hip(monkeypatch):
+    from gan_variant_research_amd import losses as L
+    from tests.test_autograd_bridge import loss_cases
+    monkeypatch.setattr(L, "_PLANS", {})
+    loss_cases(DEV, 1e-4)
+
+
+def test_training_utilities_hip(tmp_path):
+    from tests.test_autograd_bridge import training_cases
+    training_cases(DEV, 1e-5, tmp_path)
+
+
+def test_module_step_hip(monkeypatch):
+    """The reference's train_step, written against the drop-in module API, on the HIP kernels vs the oracle (steps 0-1, DiffAugment on)."""
+    from gan_variant_research_amd import losses as L
+    from tests.test_autograd_bridge import module_step_cases
+    monkeypatch.setattr(L, "_PLANS", {})
+    module_step_cases(DEV, 1e-3, 2e-3)
+
+
+@pytest.mark.parametrize("bm", ["256", "288"])
+@pytest.mark.parametrize("H", [16, 20])
+def test_conv_fused_instance_norm_statistics(bm, H, monkeypatch):
+    """Per-tile (sum, sum of squares) written by the range-patch epilogue + gan_in_stats_from_parts == InstanceNorm statistics of the
+    convolution result; both tile heights, a map with a partial last tile (H=20: 400 pixels)."""
+    from gan_variant_research_amd.convplan import ConvLayer
+    monkeypatch.setenv("GAN_PATCH_BM", bm)
+    B, Cc = 3, 256
+    tw = Twin(BF16, seed=11)
+    xc, xg = tw.view(B, H, H, Cc, 1)
+    yc, yg = tw.view(B, H, H, Cc, 0, rand=False)
+    w = torch.randn(Cc, Cc, 3, 3, generator=tw.gen) * 0.03
+    b = torch.randn(Cc, generator=tw.gen) * 0.5
+    stats, parts = [], []
+    for ctx, x, y in ((tw.c, xc, yc), (tw.g, xg, yg)):
+        dev = ctx.device
+        layer = ConvLayer(ctx, w.to(dev), b.to(dev), torch.zeros_like(w).to(dev), torch.zeros_like(b).to(dev), 3, 1, 1)
+        ws = ctx.f32(B * 96 * Cc * 2)
+        ops = layer.fwd(x, y, stats_ws=ws)
+        assert layer.stats_parts > 0
+        parts.append(layer.stats_parts)
+        st = ctx.f32(B * Cc * 2)
+        for o in layer.repack_ops() + ops + [ctx.ops.in_stats_from_parts(ws, layer.stats_parts, B, Cc, H * H, 1e-5, st)]:
+            o()
+        stats.append(st)
+    torch.cuda.synchronize()
+    assert parts[1] == -(-H * H // int(bm))
+    tw.check(2e-2, 2e-2)                       # the convolution result itself
+    sc, sg = stats[0].view(B, Cc, 2), stats[1].cpu().view(B, Cc, 2)
+    np.testing.assert_allclose(sg[..., 0].numpy(), sc[..., 0].numpy(), rtol=2e-3, atol=2e-3)   # mean
+    np.testing.assert_allclose(sg[..., 1].numpy(), sc[..., 1].numpy(), rtol=2e-3)              # rstd
+    # and they are the statistics of the (unrounded) convolution result
+    ref = torch.nn.functional.conv2d(xc.padded().float().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), b)   # the halo is part of the view
+    np.testing.assert_allclose(sg[..., 0].numpy(), ref.mean((2, 3)).numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(sg[..., 1].numpy(), (1.0 / torch.sqrt(ref.var((2, 3), unbiased=False) + 1e-5)).numpy(), rtol=2e-3)
+
+
+def test_multi_stream_step_is_deterministic(monkeypatch):
+    """Three HIP streams per step (main, weight gradients, discriminator) and no atomics anywhere: two runs from the same seeds must
+    give bit-identical losses and weights -- a race between streams shows up here as run-to-run noise."""
+    from gan_variant_research_amd import cut as C
+    import bench
+    cfg = bench.default_config()
+    cfg["model"]["generator"]["ngf"], cfg["model"]["discriminator"]["ndf"] = 32, 32
+    cfg["r1"]["every"] = 2                               # R1 inside the window
+    B, S = 4, 128
+
+    def run():
+        C.set_seed(42)
+        gen, disc = C.build_models(cfg, DEV)
+        tr = C.CutTrainer(gen, disc, cfg, B, S, device=DEV, amp=True)
+        g = torch.Generator().manual_seed(3)
+        photos = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(DEV)
+        monets = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(DEV)
+        rg = torch.Generator().manual_seed(9)
+        out = []
+        for step in range(4):
+            out.append(tr.train_step(step, photos, monets, tr.sample_randomness(rg), sync="lag" if step % 2 else True))
+        out.append(tr.flush_losses())
+        torch.cuda.synchronize()
+        return [o for o in out if o is not None], tr.opt_G.flat_p.clone(), tr.opt_D.flat_p.clone()
+    la, ga, da = run()
+    lb, gb, db = run()
+    assert la == lb, (la, lb)
+    assert torch.equal(ga, gb) and torch.equal(da, db)
+    monkeypatch.setenv("GAN_SINGLE_STREAM", "1")          # the same launches on ONE stream: concurrency must not change a bit
+    lc, gc, dc = run()
+    assert la == lc, (la, lc)
+    assert torch.equal(ga, gc) and torch.equal(da, dc)
