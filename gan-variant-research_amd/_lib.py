@@ -74,6 +74,8 @@ PROTOTYPES = {
     "gan_nchw_to_view": (C.c_int, [vp, C.c_int, PV, C.c_int, vp]),
     "gan_view_to_nchw": (C.c_int, [PV, C.c_int, vp, vp]),
     "gan_view_copy": (C.c_int, [PV, PV, C.c_int, vp]),
+    "gan_avgpool_fwd": (C.c_int, [PV, PV, vp]),
+    "gan_avgpool_bwd": (C.c_int, [PV, PV, C.c_int, vp]),
     "gan_diffaug_fwd": (C.c_int, [PV, C.c_int, vp, PV, vp, vp]),
     "gan_diffaug_bwd": (C.c_int, [PV, C.c_int, vp, PV, vp, vp]),
     "gan_patch_loss": (C.c_int, [PV, C.c_int, f32, f32, vp, PV, vp]),

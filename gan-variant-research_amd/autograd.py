@@ -101,9 +101,12 @@ class _Bridge:
         ver = (_WEIGHT_EPOCH[0],) + tuple(p._version for p in self.plist)
         if ver != self._packed_version:
             if self._repack is None:
-                self._repack = self.net.repack_program()
+                self._repack = self._repack_program()
             self._repack.run()
             self._packed_version = ver
+
+    def _repack_program(self) -> Program:
+        return self.net.repack_program()
 
     def _lease(self, key, make) -> _Slot:
         slots = self.pool.setdefault(key, [])
@@ -264,25 +267,47 @@ class _GenFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------ discriminator
 class _DiscBridge(_Bridge):
-    def __init__(self, module, device, dtype, style, prefix, ndf, n_layers):
-        self.style, self.prefix, self.ndf, self.n_layers = style, prefix, ndf, n_layers
+    """One PatchGAN discriminator (prefixes of length 1) or the scales of MultiscaleDiscriminator: scale i sees the input
+    average-pooled i times (discriminator_patchgan.py:102-116)."""
+
+    def __init__(self, module, device, dtype, style, prefixes, ndf, n_layers):
+        self.style, self.ndf, self.n_layers = style, ndf, n_layers
+        self.prefixes = [prefixes] if isinstance(prefixes, str) else list(prefixes)
         super().__init__(module, device, dtype)
 
     def _make_net(self):
-        return DiscriminatorNet(self.ctx, self.params, self.grads, self.style, self.prefix, self.ndf, self.n_layers)
+        self.nets = [DiscriminatorNet(self.ctx, self.params, self.grads, self.style, p, self.ndf, self.n_layers) for p in self.prefixes]
+        return self.nets[0]
+
+    def _repack_program(self) -> Program:
+        prog = Program("D.repack")
+        for net in self.nets:
+            prog.add(net.repack_program())
+        return prog
+
+    def _passes(self, B, H, W):
+        dps = []
+        for net in self.nets:
+            dps.append(net.new_pass(B, H, W))
+            H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1       # AvgPool2d(3, 2, 1)
+        return dps
 
     def _make_slot(self, B, H, W):
-        ctx, ops, net = self.ctx, self.ctx.ops, self.net
+        ops, net = self.ctx.ops, self.net
         s = _Slot()
-        s.dp = net.new_pass(B, H, W)
+        s.dps = self._passes(B, H, W)
         s.xin = torch.zeros(B, net.in_c, H, W, dtype=torch.float32, device=self.device)
         s.fwd = Program("D.autograd.fwd")
-        s.fwd.add(ops.nchw_to_view(s.xin, net.in_c, s.dp.x, HALO_ZERO))
-        s.fwd.add(s.dp.fwd_program())
-        lg = s.dp.logits
-        s.out = torch.zeros(B, 1, lg.H, lg.W, dtype=torch.float32, device=self.device)
-        s.fwd.add(ops.view_to_nchw(lg, 1, s.out))
-        s.g_out = torch.zeros_like(s.out)
+        s.fwd.add(ops.nchw_to_view(s.xin, net.in_c, s.dps[0].x, HALO_ZERO))
+        s.outs, s.g_outs = [], []
+        for i, dp in enumerate(s.dps):
+            if i > 0:
+                s.fwd.add(ops.avgpool_fwd(s.dps[i - 1].x, dp.x))
+            s.fwd.add(dp.fwd_program())
+            lg = dp.logits
+            s.outs.append(torch.zeros(B, 1, lg.H, lg.W, dtype=torch.float32, device=self.device))
+            s.fwd.add(ops.view_to_nchw(lg, 1, s.outs[-1]))
+            s.g_outs.append(torch.zeros_like(s.outs[-1]))
         s.gx = torch.zeros_like(s.xin)
         return s
 
@@ -294,29 +319,33 @@ class _DiscBridge(_Bridge):
             self._sync_weights()
             s.xin.copy_(x)
             s.fwd.run()
-            out = s.out.clone()
+            outs = tuple(o.clone() for o in s.outs)
         except BaseException:
             s.busy = False
             raise
         if not keep:
             s.busy = False
-        return s, out
+        return s, outs
 
-    def backward(self, s: _Slot, g: torch.Tensor, need_x: bool, need_w: bool):
-        ops, dp = self.ctx.ops, s.dp
+    def backward(self, s: _Slot, gs: Sequence[torch.Tensor], need_x: bool, need_w: bool):
+        ops = self.ctx.ops
         key = (need_x, need_w)
         prog = s.bwd.get(key)
         if prog is None:
             prog = Program("D.autograd.bwd")
-            gl = dp.grad_logits_view()
-            prog.add(ops.nchw_to_view(s.g_out, 1, gl, HALO_ZERO))
-            prog.add(dp.bwd_program(gl, wgrad=need_w, accumulate=False, need_input_grad=need_x))
+            for dp, g_out in zip(s.dps, s.g_outs):
+                gl = dp.grad_logits_view()
+                prog.add(ops.nchw_to_view(g_out, 1, gl, HALO_ZERO))
+                prog.add(dp.bwd_program(gl, wgrad=need_w, accumulate=False, need_input_grad=need_x))
             if need_x:
-                prog.add(ops.view_to_nchw(dp.g_input, self.net.in_c, s.gx))
+                for i in range(len(s.dps) - 2, -1, -1):      # dL/dx_i += pool^T dL/dx_{i+1}
+                    prog.add(ops.avgpool_bwd(s.dps[i + 1].g_input, s.dps[i].g_input, True))
+                prog.add(ops.view_to_nchw(s.dps[0].g_input, self.net.in_c, s.gx))
             s.bwd[key] = prog
             self._repack, self._packed_version = None, None
             self._sync_weights()
-        s.g_out.copy_(g)
+        for dst, g in zip(s.g_outs, gs):
+            dst.copy_(g)
         prog.run()
         return s.gx.clone() if need_x else None
 
@@ -324,20 +353,20 @@ class _DiscBridge(_Bridge):
 class _DiscFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, bridge: _DiscBridge, keep, x, *params):
-        slot, out = bridge.forward(x.detach(), keep)
+        slot, outs = bridge.forward(x.detach(), keep)
         ctx.bridge = bridge
         if keep:
             ctx.slot, ctx.lease = slot, _Lease(slot)
             ctx.save_for_backward(x)
             slot.node = weakref.ref(ctx)
-        return out
+        return outs
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         ctx.saved_tensors
         b = ctx.bridge
         need_w = any(ctx.needs_input_grad[3:])
-        gx = b.backward(ctx.slot, g.detach().float().contiguous(), ctx.needs_input_grad[2], need_w)
+        gx = b.backward(ctx.slot, [g.detach().float().contiguous() for g in gs], ctx.needs_input_grad[2], need_w)
         return (None, None, gx) + (b.param_grads(ctx.needs_input_grad[3:]) if need_w else (None,) * len(b.plist))
 
 
@@ -363,11 +392,13 @@ def generator_forward(module, x: torch.Tensor, style: str, feat_ids: Optional[Se
     return outs[0] if ids is None else list(outs)
 
 
-def discriminator_forward(module, x: torch.Tensor, style: str, prefix: str, ndf: int, n_layers: int) -> torch.Tensor:
-    """PatchGANDiscriminator.forward (discriminator_patchgan.py:56-63) / NLayerDiscriminator.forward with autograd."""
+def discriminator_forward(module, x: torch.Tensor, style: str, prefix, ndf: int, n_layers: int):
+    """PatchGANDiscriminator.forward (discriminator_patchgan.py:56-63) / NLayerDiscriminator.forward with autograd; with a list of
+    prefixes, MultiscaleDiscriminator.forward (:102-116): the list of per-scale logits from ONE autograd node."""
     b = _bridge_of(module, lambda dev, dt: _DiscBridge(module, dev, dt, style, prefix, ndf, n_layers))
     keep = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in b.plist))
-    return _DiscFn.apply(b, keep, x.float().contiguous(), *b.plist)
+    outs = _DiscFn.apply(b, keep, x.float().contiguous(), *b.plist)
+    return outs[0] if isinstance(prefix, str) else list(outs)
 
 
 # ------------------------------------------------------------------------------------------------ R1 (double backward)
@@ -384,11 +415,11 @@ class _R1Fn(torch.autograd.Function):
             s.xin.copy_(x)
             s.prog.run()
             loss = s.loss.clone().reshape(())
-            last_bias = bridge.net.convs[-1].grad_b
+            last_biases = [net.convs[-1].grad_b for net in bridge.nets]
             grads = []
             for k in bridge.names:
                 g = bridge.grads[k]
-                if g is last_bias:
+                if any(g is lb for lb in last_biases):
                     grads.append(None)                        # the reference's graph never reaches the last bias
                 elif k.endswith(".bias"):
                     grads.append(torch.zeros_like(g))         # d/db of an input gradient is zero
@@ -405,16 +436,30 @@ class _R1Fn(torch.autograd.Function):
 
 
 def _r1_slot(bridge: _DiscBridge, B, H, W) -> _Slot:
-    ops, net = bridge.ctx.ops, bridge.net
+    """With K scales D_total(x) = sum_i sum D_i(P^i x) (P = the average pool), so g = sum_i (P^i)^T g_i and
+    d r1 / d theta_i = <(2/B) P^i g, d g_i / d theta_i>: every scale runs its own first-order half, the input gradients are
+    folded back through the pools into g, and each scale's second-order half is seeded with g pooled down to its resolution."""
+    ctx, ops, net = bridge.ctx, bridge.ctx.ops, bridge.net
     s = _Slot()
-    s.dp = net.new_pass(B, H, W)
+    s.dps = bridge._passes(B, H, W)
     s.xin = torch.zeros(B, net.in_c, H, W, dtype=torch.float32, device=bridge.device)
-    s.loss = bridge.ctx.f32(1)
-    s.scratch = bridge.ctx.f32(1)
+    s.loss = ctx.f32(1)
+    s.scratch = ctx.f32(1)
     s.prog = Program("R1.autograd")
-    s.prog.add(ops.nchw_to_view(s.xin, net.in_c, s.dp.x, HALO_ZERO))
-    s.prog.add(s.dp.fwd_program())
-    s.prog.add(s.dp.r1_program(1.0, s.loss, s.scratch))
+    s.prog.add(ops.nchw_to_view(s.xin, net.in_c, s.dps[0].x, HALO_ZERO))
+    for i, dp in enumerate(s.dps):
+        if i > 0:
+            s.prog.add(ops.avgpool_fwd(s.dps[i - 1].x, dp.x))
+        s.prog.add(dp.fwd_program())
+        s.prog.add(dp.r1_first(s.scratch))
+    for i in range(len(s.dps) - 2, -1, -1):
+        s.prog.add(ops.avgpool_bwd(s.dps[i + 1].g_input, s.dps[i].g_input, True))
+    us = [ctx.view(B, dp.H, dp.W, dp.x.C, 1) for dp in s.dps]
+    s.prog.add(ops.r1_reduce(s.dps[0].g_input, net.in_c, 1.0, s.loss, us[0], ctx.scratch("r1_ws", 1024)))
+    for i, dp in enumerate(s.dps):
+        if i > 0:
+            s.prog.add(ops.avgpool_fwd(us[i - 1], us[i]))
+        s.prog.add(dp.r1_second(us[i]))
     return s
 
 
@@ -426,6 +471,6 @@ def r1_regularization(discriminator, real_images: torch.Tensor, amp_ctx=None) ->
     b = getattr(d0, "_hip_bridge_r1", None)
     p = next(d0.parameters())
     if b is None or b.device != p.device:
-        b = _DiscBridge(d0, p.device, F32, "cut", "discriminators.0.model.", d0.ndf, d0.n_layers)
+        b = _DiscBridge(d0, p.device, F32, "cut", [f"discriminators.{i}.model." for i in range(getattr(d0, "num_scales", 1))], d0.ndf, d0.n_layers)
         object.__setattr__(d0, "_hip_bridge_r1", b)
     return _R1Fn.apply(b, real_images.detach().float().contiguous(), *b.plist)

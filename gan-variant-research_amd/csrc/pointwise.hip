@@ -309,3 +309,117 @@ extern "C" int gan_r1_reduce(const gan_view* g, int C, float scale, float* loss,
   GAN_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------ AvgPool2d(3, stride 2, padding 1, count_include_pad=False)
+// The downsampling between the scales of MultiscaleDiscriminator (GAN_Variant1/models/discriminator_patchgan.py:100, 110-112):
+// every output pixel is the mean of the taps of its 3x3 window that fall inside the image.  One 16-byte chunk per lane.
+namespace {
+template <typename T>
+__global__ void avgpool_fwd_kernel(DView x, DView y) {
+  constexpr int N = Chunk<T>::N;
+  const int nck = y.C / N;
+  const int64_t total = (int64_t)y.B * y.H * y.W * nck;
+  const T* xp = reinterpret_cast<const T*>(x.ptr);
+  T* yp = reinterpret_cast<T*>(y.ptr);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ck = (int)(i % nck);
+    int64_t r = i / nck;
+    const int ox = (int)(r % y.W); r /= y.W;
+    const int oy = (int)(r % y.H);
+    const int b = (int)(r / y.H);
+    float s[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) s[e] = 0.f;
+    int cnt = 0;
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int iy = 2 * oy + dy;
+      if (iy < 0 || iy >= x.H) continue;
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int ix = 2 * ox + dx;
+        if (ix < 0 || ix >= x.W) continue;
+        float v[N];
+        Chunk<T>::load(xp + x.pix(b, iy, ix) + ck * N, v);
+#pragma unroll
+        for (int e = 0; e < N; ++e) s[e] += v[e];
+        ++cnt;
+      }
+    }
+    const float d = (float)cnt;
+#pragma unroll
+    for (int e = 0; e < N; ++e) s[e] = s[e] / d;
+    Chunk<T>::store(yp + y.pix(b, oy, ox) + ck * N, s);
+  }
+}
+
+__device__ __forceinline__ int pool_taps(int o, int n) {   // taps of output index o that lie in [0, n)
+  return (2 * o - 1 >= 0 ? 1 : 0) + 1 + (2 * o + 1 < n ? 1 : 0);
+}
+
+template <typename T>
+__global__ void avgpool_bwd_kernel(DView gy, DView gx, int accumulate) {
+  constexpr int N = Chunk<T>::N;
+  const int nck = gx.C / N;
+  const int64_t total = (int64_t)gx.B * gx.H * gx.W * nck;
+  const T* gp = reinterpret_cast<const T*>(gy.ptr);
+  T* xp = reinterpret_cast<T*>(gx.ptr);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ck = (int)(i % nck);
+    int64_t r = i / nck;
+    const int ix = (int)(r % gx.W); r /= gx.W;
+    const int iy = (int)(r % gx.H);
+    const int b = (int)(r / gx.H);
+    float s[N];
+    T* dst = xp + gx.pix(b, iy, ix) + ck * N;
+    if (accumulate) Chunk<T>::load(dst, s);
+    else {
+#pragma unroll
+      for (int e = 0; e < N; ++e) s[e] = 0.f;
+    }
+    // outputs whose window covers input pixel i: 2o-1 <= i <= 2o+1  <=>  o in {ceil((i-1)/2) .. floor((i+1)/2)}
+    for (int oy = iy >> 1; oy <= (iy + 1) >> 1; ++oy) {
+      if (oy >= gy.H) continue;
+      const int ny = pool_taps(oy, gx.H);
+      for (int ox = ix >> 1; ox <= (ix + 1) >> 1; ++ox) {
+        if (ox >= gy.W) continue;
+        const float inv = 1.f / (float)(ny * pool_taps(ox, gx.W));
+        float v[N];
+        Chunk<T>::load(gp + gy.pix(b, oy, ox) + ck * N, v);
+#pragma unroll
+        for (int e = 0; e < N; ++e) s[e] += v[e] * inv;
+      }
+    }
+    Chunk<T>::store(dst, s);
+  }
+}
+}  // namespace
+
+static int avgpool_check(const gan_view* big, const gan_view* small, const char* what) {
+  GAN_CHECK(big->B == small->B && big->C == small->C && big->dtype == small->dtype, "%s: batch / channel / dtype mismatch", what);
+  GAN_CHECK(small->H == (big->H - 1) / 2 + 1 && small->W == (big->W - 1) / 2 + 1, "%s: pooled size must be ((H-1)/2+1, (W-1)/2+1) = (%d,%d), got (%d,%d)",
+            what, (big->H - 1) / 2 + 1, (big->W - 1) / 2 + 1, small->H, small->W);
+  return 0;
+}
+
+extern "C" int gan_avgpool_fwd(const gan_view* x, const gan_view* y, void* stream) {
+  VCHK(x, "avgpool_fwd.x"); VCHK(y, "avgpool_fwd.y");
+  if (avgpool_check(x, y, "avgpool_fwd")) return -1;
+  const int epc = y->dtype == GAN_F32 ? 4 : 8;
+  const int64_t total = (int64_t)y->B * y->H * y->W * (y->C / epc);
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  DView vx = to_dview(x), vy = to_dview(y);
+  GAN_DISPATCH_DTYPE(y->dtype, hipLaunchKernelGGL((avgpool_fwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, vx, vy);)
+  GAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gan_avgpool_bwd(const gan_view* gy, const gan_view* gx, int accumulate, void* stream) {
+  VCHK(gy, "avgpool_bwd.gy"); VCHK(gx, "avgpool_bwd.gx");
+  if (avgpool_check(gx, gy, "avgpool_bwd")) return -1;
+  const int epc = gx->dtype == GAN_F32 ? 4 : 8;
+  const int64_t total = (int64_t)gx->B * gx->H * gx->W * (gx->C / epc);
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  DView vg = to_dview(gy), vx = to_dview(gx);
+  GAN_DISPATCH_DTYPE(gx->dtype, hipLaunchKernelGGL((avgpool_bwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, vg, vx, accumulate);)
+  GAN_LAUNCH_CHECK();
+  return 0;
+}

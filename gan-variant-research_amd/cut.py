@@ -107,16 +107,17 @@ class MultiscaleDiscriminator(nn.Module):
 
     def __init__(self, input_nc=3, ndf=64, n_layers=3, num_scales=3, use_spectral_norm=True):
         super().__init__()
-        if num_scales != 1 or use_spectral_norm:
-            raise NotImplementedError("MI355X path implements the baseline config: num_scales=1, use_spectral_norm=False")
+        if use_spectral_norm:
+            raise NotImplementedError("use_spectral_norm=True is not built on the MI355X path (off in configs/train_gan_cutpp.yaml)")
         self.input_nc, self.ndf, self.n_layers, self.num_scales = input_nc, ndf, n_layers, num_scales
-        self.discriminators = nn.ModuleList([_PatchGANParams(input_nc, ndf, n_layers)])
+        self.discriminators = nn.ModuleList([_PatchGANParams(input_nc, ndf, n_layers) for _ in range(num_scales)])
         self.compute_dtype = F32
 
     def forward(self, x):
-        """discriminator_patchgan.py:102-116: list of per-scale logits (one scale), differentiable (autograd.py)."""
+        """discriminator_patchgan.py:102-116: list of per-scale logits, scale i on the input average-pooled i times
+        (AvgPool2d(3, 2, 1, count_include_pad=False), :100); differentiable, one autograd node (autograd.py)."""
         from . import autograd as AG
-        return [AG.discriminator_forward(self, x, "cut", "discriminators.0.model.", self.ndf, self.n_layers)]
+        return AG.discriminator_forward(self, x, "cut", [f"discriminators.{i}.model." for i in range(self.num_scales)], self.ndf, self.n_layers)
 
 
 def build_models(config, device):
@@ -330,6 +331,9 @@ class CutTrainer:
         self.policy = config["diffaugment"].get("policy", ["color", "translation", "cutout"]) if config["diffaugment"].get("enable", False) else None
         self.aug = DiffAugment(self.policy) if self.policy is not None else None
         self.generator, self.discriminator = generator, discriminator
+        if getattr(discriminator, "num_scales", 1) != 1 or getattr(discriminator, "use_spectral_norm", False):
+            raise NotImplementedError("the fused CutTrainer runs the reference configuration (one discriminator scale, no spectral norm); "
+                                      "module_step.train_step drives the optional discriminator variants on the same kernels")
 
         # ---- parameters -> flat fp32 blocks (master weights, grads, Adam moments, EMA shadow)
         gsd = {k: v.detach().to(self.device, torch.float32) for k, v in generator.state_dict().items()}

@@ -350,16 +350,32 @@ class DPass:
         first-order input gradient with the LeakyReLU masks fused in the dgrad epilogues (delta_i kept per layer), then the
         linearised forward u_i = mask_i * (W_i * u_{i-1}) seeded with u_0 = scale * 2 g / B, with dW_i = wgrad(u_{i-1}, delta_i).
         Bias gradients are zero except the last bias, whose gradient is None in the reference (the caller skips it)."""
-        net, ctx, ops, B = self.net, self.net.ctx, self.net.ctx.ops, self.B
-        assert net.style == "cut", "R1 is part of the CUT trainer (no norm layers in its discriminator)"
+        ctx, ops = self.net.ctx, self.net.ctx.ops
         pr = Program("R1")
+        pr.add(self.r1_first(scratch))
+        u = ctx.view(self.B, self.H, self.W, self.x.C, 1)
+        pr.add(ops.r1_reduce(self.g_input, self.net.in_c, scale, loss, u, ctx.scratch("r1_ws", 1024)))
+        pr.add(self.r1_second(u))
+        return pr
+
+    def r1_first(self, scratch: torch.Tensor) -> Program:
+        """First-order half of R1: g = d sum D(x) / dx into self.g_input, the per-layer output gradients kept for r1_second."""
+        net, ops, B = self.net, self.net.ctx.ops, self.B
+        assert net.style == "cut", "R1 is part of the CUT trainer (no norm layers in its discriminator)"
+        pr = Program("R1.first")
         lg = self.logits
         ones = net.gbuf("r1_ones", B, lg.H, lg.W, lg.C, 2)
         pr.add(ops.patch_loss(lg, 2, 0.0, -float(B * lg.H * lg.W), scratch, ones))   # d(sum D)/dlogits = 1
-        deltas: List[View] = []
-        pr.add(self.bwd_program(ones, wgrad=False, need_input_grad=True, keep=deltas))
-        u = ctx.view(B, self.H, self.W, self.x.C, 1)
-        pr.add(ops.r1_reduce(self.g_input, net.in_c, scale, loss, u, ctx.scratch("r1_ws", 1024)))
+        self._r1_deltas: List[View] = []
+        pr.add(self.bwd_program(ones, wgrad=False, need_input_grad=True, keep=self._r1_deltas))
+        return pr
+
+    def r1_second(self, u: View) -> Program:
+        """Second-order half: the weight gradients of <u_0, g(theta)> by the linearised forward from u_0 = `u` (zero halo 1).
+        With several scales u_0 is the pooled total input gradient, not this scale's own (autograd.py, _r1_slot)."""
+        net, ctx, B = self.net, self.net.ctx, self.B
+        pr = Program("R1.second")
+        deltas = self._r1_deltas
         for li, conv in enumerate(net.convs):
             delta = deltas[len(deltas) - 1 - li]
             pr.add(conv.wgrad(u, delta, accumulate=False, bias_too=False))

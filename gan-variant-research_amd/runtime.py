@@ -346,6 +346,12 @@ class HipOps:
     def view_copy(self, src: View, dst: View, halo_mode) -> Op:
         return self._call("gan_view_copy", self._v(src), self._v(dst), halo_mode, self._s())
 
+    def avgpool_fwd(self, x: View, y: View) -> Op:
+        return self._call("gan_avgpool_fwd", self._v(x), self._v(y), self._s())
+
+    def avgpool_bwd(self, gy: View, gx: View, accumulate: bool) -> Op:
+        return self._call("gan_avgpool_bwd", self._v(gy), self._v(gx), int(accumulate), self._s())
+
     # ---- augmentation and losses
     def diffaug_fwd(self, x: View, Cr, prm, y: View, ws) -> Op:
         return self._call("gan_diffaug_fwd", self._v(x), Cr, self._p(prm), self._v(y), self._p(ws), self._s())

@@ -148,6 +148,12 @@ int gan_nchw_to_view(const float* src, int C, const gan_view* dst, int halo_mode
 int gan_view_to_nchw(const gan_view* src, int C, float* dst, void* stream);
 int gan_view_copy(const gan_view* src, const gan_view* dst, int halo_mode, void* stream);   /* interior copy + halo fill */
 
+/* ---- AvgPool2d(kernel 3, stride 2, padding 1, count_include_pad=False): the downsampling between the scales of
+ *      MultiscaleDiscriminator (GAN_Variant1/models/discriminator_patchgan.py:100, 110-112; get_intermediate_features :125-127).
+ *      y is ((H-1)/2+1) x ((W-1)/2+1); only interiors are written (zero halos stay zero).  bwd: gx (+)= pool^T gy. */
+int gan_avgpool_fwd(const gan_view* x, const gan_view* y, void* stream);
+int gan_avgpool_bwd(const gan_view* gy, const gan_view* gx, int accumulate, void* stream);
+
 /* ---- DiffAugment (GAN_Variant1/training/diffaugment.py:6-60,94-106), per-sample parameters injected.
  *      prm = device fp32 [B][12]: brightness add, saturation factor, contrast factor, tx, ty,
  *      cut_lo_h, cut_hi_h, cut_lo_w, cut_hi_w (inclusive; lo>hi = no cutout), 3 spare.  C = real channels (3). */

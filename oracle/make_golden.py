@@ -213,9 +213,70 @@ def gen_basic():
     np.savez_compressed(os.path.join(OUT, "basic.npz"), **_np(out))
 
 
+def gen_optional(tc):
+    """Architecture switches that are off in train_gan_cutpp.yaml but are the constructor defaults: the multiscale
+    discriminator (num_scales=3, AvgPool2d(3,2,1,count_include_pad=False) between scales) and spectral normalisation
+    (torch.nn.utils.spectral_norm: one power iteration per training-mode forward).  ndf=4 keeps the vectors small."""
+    from GAN_Variant1.losses.adv_hinge import discriminator_hinge_loss, generator_hinge_loss
+    from GAN_Variant1.models.discriminator_patchgan import MultiscaleDiscriminator
+    from GAN_Variant1.utils.amp_utils import AMPContext
+    from GAN_Variant1.utils.seed_dist import set_seed
+
+    out = {}
+    amp = AMPContext(enabled=False)
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(2, 3, 96, 96, generator=g) * 2 - 1
+    y = torch.rand(2, 3, 96, 96, generator=g) * 2 - 1
+    out["x"], out["y"] = x, y
+
+    def record(tag, D, train_calls):
+        for k, v in D.state_dict().items():
+            out[f"{tag}.sd.{k}"] = v.clone()
+        xr = x.clone().requires_grad_(True)
+        for _ in range(train_calls - 1):          # extra training-mode forwards: each one advances the power iteration
+            D(x)
+        outs = D(xr)
+        for i, o in enumerate(outs):
+            out[f"{tag}.out{i}"] = o.detach().clone()
+        loss = discriminator_hinge_loss(outs, D(y)) + 0.25 * generator_hinge_loss(outs)
+        out[f"{tag}.loss"] = loss.detach()
+        names = [k for k, _ in D.named_parameters()]
+        grads = torch.autograd.grad(loss, [xr] + [p for _, p in D.named_parameters()])
+        out[f"{tag}.gx"] = grads[0]
+        for k, gr in zip(names, grads[1:]):
+            out[f"{tag}.gw.{k}"] = gr
+        for k, v in D.state_dict().items():
+            if k.endswith("_u") or k.endswith("_v"):
+                out[f"{tag}.sd_after.{k}"] = v.clone()
+        # R1 exactly as the trainer calls it (train_cutpp.py:258-262)
+        for p_ in D.parameters():
+            p_.grad = None
+        r1 = tc.r1_regularization(D, x.clone(), amp)
+        out[f"{tag}.r1"] = r1.detach()
+        r1.backward()
+        for k, p_ in D.named_parameters():
+            out[f"{tag}.r1.gw.{k}"] = torch.zeros(0) if p_.grad is None else p_.grad.clone()
+        D.eval()
+        with torch.no_grad():
+            for i, o in enumerate(D(x)):
+                out[f"{tag}.eval_out{i}"] = o.clone()
+        D.train()
+
+    set_seed(5)
+    record("ms3", MultiscaleDiscriminator(3, 4, 3, num_scales=3, use_spectral_norm=False), 1)
+    set_seed(6)
+    record("sn2", MultiscaleDiscriminator(3, 4, 3, num_scales=2, use_spectral_norm=True), 2)
+    np.savez_compressed(os.path.join(OUT, "cut_optional.npz"), **_np(out))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     tc = _import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "optional":
+        gen_optional(tc)
+        print("cut_optional.npz", os.path.getsize(os.path.join(OUT, "cut_optional.npz")))
+        return
+    gen_optional(tc)
     gen_models(tc)
     gen_losses(tc)
     gen_optim(tc)

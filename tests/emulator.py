@@ -10,6 +10,7 @@ from __future__ import annotations
 import math
 
 import torch
+import torch.nn.functional as F
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 HALO_NONE, HALO_ZERO, HALO_REFLECT = 0, 1, 2
@@ -343,6 +344,22 @@ class EmuOps:
                 _store(dst, v[:, ys][:, :, xs], padded_coords=True)
             else:
                 _store(dst, v)
+        return op
+
+    def avgpool_fwd(self, x, y):
+        def op():
+            v = x.nhwc().float().permute(0, 3, 1, 2)
+            _store(y, F.avg_pool2d(v, 3, 2, 1, count_include_pad=False).permute(0, 2, 3, 1))
+        return op
+
+    def avgpool_bwd(self, gy, gx, accumulate):
+        def op():
+            with torch.enable_grad():
+                probe = torch.zeros(gx.B, gx.C, gx.H, gx.W, dtype=torch.float32, requires_grad=True)
+                out = F.avg_pool2d(probe, 3, 2, 1, count_include_pad=False)
+                g, = torch.autograd.grad(out, probe, gy.nhwc().float().permute(0, 3, 1, 2))
+            g = g.permute(0, 2, 3, 1)
+            _store(gx, gx.nhwc().float() + g if accumulate else g)
         return op
 
     # ------------------------------------------------------------------ augmentation and losses

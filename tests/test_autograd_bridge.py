@@ -126,6 +126,62 @@ def bridge_cases(device, tol):
         _close(prm.grad, pdb[k].grad, tol * 10, f"Basic D grad {k}")
 
 
+def optional_cases(device, tol, tags=("ms3", "sn2")):
+    """Architecture switches that are the reference constructors' defaults but off in its YAML, against vectors the
+    reference itself produced (tests/golden/cut_optional.npz, oracle/make_golden.py:gen_optional): outputs per scale, the loss of
+    a hinge D-step + G-step mix, its input and parameter gradients, R1 with its second-order parameter gradients, eval mode."""
+    import os
+    from gan_variant_research_amd import losses as L
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cut_optional.npz"))
+    T = lambda k: torch.from_numpy(np.asarray(g[k])).to(device)
+    for tag in tags:
+        ns, sn = (3, False) if tag == "ms3" else (2, True)
+        D = C.MultiscaleDiscriminator(3, 4, 3, num_scales=ns, use_spectral_norm=sn).to(device)
+        sd = {k[len(tag) + 4:]: T(k) for k in g.files if k.startswith(f"{tag}.sd.")}
+        assert list(D.state_dict()) == list(sd), "state_dict keys / order"
+        D.load_state_dict(sd)
+        x, y = T("x"), T("y")
+        if sn:
+            D(x)                                        # the golden ran one extra training-mode forward first
+        xr = x.clone().requires_grad_(True)
+        outs = D(xr)
+        assert isinstance(outs, list) and len(outs) == ns
+        for i, o in enumerate(outs):
+            _close(o, T(f"{tag}.out{i}"), tol, f"{tag} out{i}")
+        loss = L.discriminator_hinge_loss(outs, D(y)) + 0.25 * L.generator_hinge_loss(outs)
+        _close(loss, T(f"{tag}.loss"), tol, f"{tag} loss")
+        names = [k for k, _ in D.named_parameters()]
+        grads = torch.autograd.grad(loss, [xr] + [p for _, p in D.named_parameters()])
+        _close(grads[0], T(f"{tag}.gx"), tol * 5, f"{tag} dL/dx")
+        for k, gr in zip(names, grads[1:]):
+            _close(gr, T(f"{tag}.gw.{k}"), tol * 5, f"{tag} grad {k}")
+        for k, v in D.state_dict().items():
+            if k.endswith("_u") or k.endswith("_v"):
+                _close(v, T(f"{tag}.sd_after.{k}"), tol, f"{tag} buffer {k} after the forwards")
+        D.zero_grad()
+        r1 = AG.r1_regularization(D, x.clone())
+        _close(r1, T(f"{tag}.r1"), tol * 2, f"{tag} r1")
+        r1.backward()
+        for k, p_ in D.named_parameters():
+            want = T(f"{tag}.r1.gw.{k}")
+            if want.numel() == 0:
+                assert p_.grad is None, f"{tag}: {k} must have no R1 gradient"
+            else:
+                _close(p_.grad, want, tol * 10, f"{tag} R1 grad {k}")
+        D.eval()
+        with torch.no_grad():
+            for i, o in enumerate(D(x)):
+                _close(o, T(f"{tag}.eval_out{i}"), tol, f"{tag} eval out{i}")
+        D.train()
+
+
+def test_multiscale_discriminator_on_emulator(monkeypatch):
+    monkeypatch.setattr(AG, "_OPS_FACTORY", lambda device: EmuOps())
+    from gan_variant_research_amd import losses as L
+    monkeypatch.setattr(L, "_PLANS", {})
+    optional_cases(torch.device("cpu"), 2e-4, tags=("ms3",))
+
+
 def test_autograd_bridge_on_emulator(monkeypatch):
     monkeypatch.setattr(AG, "_OPS_FACTORY", lambda device: EmuOps())
     bridge_cases(torch.device("cpu"), 2e-4)

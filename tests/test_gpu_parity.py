@@ -163,6 +163,23 @@ def test_layout_and_losses_twins(dtype):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("hw", [(24, 24), (25, 31), (7, 2), (1, 1)])
+def test_avgpool_twins(hw, dtype):
+    """AvgPool2d(3, 2, 1, count_include_pad=False) forward / transpose (multiscale discriminator), even, odd and degenerate sizes."""
+    B, (H, W) = 2, hw
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    tw = Twin(dtype)
+    xc, xg = tw.view(B, H, W, 8, 1)
+    yc, yg = tw.view(B, Ho, Wo, 8, 1, rand=False)
+    tw.run(tw.c.ops.avgpool_fwd(xc, yc), tw.g.ops.avgpool_fwd(xg, yg))
+    gyc, gyg = tw.view(B, Ho, Wo, 8, 0)
+    for acc in (False, True):
+        gxc, gxg = tw.view(B, H, W, 8, 0, rand=acc)
+        tw.run(tw.c.ops.avgpool_bwd(gyc, gxc, acc), tw.g.ops.avgpool_bwd(gyg, gxg, acc))
+    tw.check(*([1e-5, 1e-6] if dtype == F32 else [1e-2, 1e-2]))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 1, 256), (3, 8, 8, 256, 1, 64), (2, 12, 12, 128, 0, 144),   # MFMA tiling
                                    (2, 12, 12, 32, 0, 100), (2, 8, 8, 512, 1, 48)])                            # scalar-FMA fallback
 def test_patchnce_twins(shape, dtype):
@@ -251,6 +268,14 @@ def test_autograd_bridge_hip():
     """G(x), get_feature_layers, D(x), r1_regularization as differentiable nn.Module calls on the HIP kernels vs the oracle under autograd."""
     from tests.test_autograd_bridge import bridge_cases
     bridge_cases(DEV, 5e-4)
+
+
+def test_multiscale_discriminator_hip(monkeypatch):
+    """MultiscaleDiscriminator(num_scales=3) -- outputs, gradients, R1 through the pooled scales -- vs vectors produced by the reference."""
+    from gan_variant_research_amd import losses as L
+    from tests.test_autograd_bridge import optional_cases
+    monkeypatch.setattr(L, "_PLANS", {})
+    optional_cases(torch.device(DEV), 5e-4, tags=("ms3",))
 
 
 def test_loss_callables_hip(monkeypatch):
