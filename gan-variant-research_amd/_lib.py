@@ -75,6 +75,9 @@ PROTOTYPES = {
     "gan_view_to_nchw": (C.c_int, [PV, C.c_int, vp, vp]),
     "gan_view_copy": (C.c_int, [PV, PV, C.c_int, vp]),
     "gan_avgpool_fwd": (C.c_int, [PV, PV, vp]),
+    "gan_spectral_norm_ws_floats": (C.c_int64, [C.c_int, C.c_int]),
+    "gan_spectral_norm_fwd": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_float, vp, vp, vp, vp]),
+    "gan_spectral_norm_bwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "gan_avgpool_bwd": (C.c_int, [PV, PV, C.c_int, vp]),
     "gan_diffaug_fwd": (C.c_int, [PV, C.c_int, vp, PV, vp, vp]),
     "gan_diffaug_bwd": (C.c_int, [PV, C.c_int, vp, PV, vp, vp]),

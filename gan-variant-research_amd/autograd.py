@@ -275,9 +275,25 @@ class _DiscBridge(_Bridge):
         self.prefixes = [prefixes] if isinstance(prefixes, str) else list(prefixes)
         super().__init__(module, device, dtype)
 
+    SN_EPS = 1e-12          # torch.nn.utils.spectral_norm default
+
     def _make_net(self):
-        self.nets = [DiscriminatorNet(self.ctx, self.params, self.grads, self.style, p, self.ndf, self.n_layers) for p in self.prefixes]
+        # spectral norm (discriminator_patchgan.py:21-23): the parameters are `weight_orig`; the convolutions run on
+        # W_sn = weight_orig / sigma, which is recomputed -- with one power iteration in training mode -- by EVERY forward.  Two
+        # live forwards therefore hold different weights, so the normalised weights, their operand copies and the (u, v, sigma)
+        # the backward needs belong to the pass slot, not to the bridge (see _slot_weights).
+        self.conv_keys = [k[:-len(".weight_orig")] for k in self.names if k.endswith(".weight_orig")]
+        self.sn = bool(self.conv_keys)
+        if self.sn:
+            self.bufs = dict(self.module.named_buffers())
+            for k in self.conv_keys:
+                self.grads[k + ".weight"] = torch.zeros_like(self.params[k + ".weight_orig"])     # dL/dW_sn, written by the wgrad kernels
+                self.params[k + ".weight"] = torch.zeros_like(self.params[k + ".weight_orig"])    # shape template for the bridge-level plan
+        self.nets = self._build_nets(self.params)
         return self.nets[0]
+
+    def _build_nets(self, params):
+        return [DiscriminatorNet(self.ctx, params, self.grads, self.style, p, self.ndf, self.n_layers) for p in self.prefixes]
 
     def _repack_program(self) -> Program:
         prog = Program("D.repack")
@@ -285,9 +301,62 @@ class _DiscBridge(_Bridge):
             prog.add(net.repack_program())
         return prog
 
-    def _passes(self, B, H, W):
+    def _slot_weights(self, s: _Slot):
+        """Without spectral norm a slot shares the bridge's networks.  With it, the slot owns W_sn, the operand copies made from
+        it and snapshots of u, v, sigma, and two programs (training / eval) that produce them from weight_orig."""
+        if not self.sn:
+            s.nets = self.nets
+            return
+        ctx, ops = self.ctx, self.ctx.ops
+        params = dict(self.params)
+        s.sn_state = {}
+        for k in self.conv_keys:
+            W = self.params[k + ".weight_orig"]
+            h, w = W.shape[0], W.numel() // W.shape[0]
+            st = {"W": W, "Wsn": torch.zeros_like(W), "u": ctx.f32(h), "v": ctx.f32(w), "sigma": ctx.f32(1),
+                  "ws": ctx.f32(ops.spectral_norm_ws_floats(h, w)), "u_buf": self.bufs[k + ".weight_u"], "v_buf": self.bufs[k + ".weight_v"]}
+            params[k + ".weight"] = st["Wsn"]
+            s.sn_state[k] = st
+        s.nets = self._build_nets(params)
+        s.sn_fwd = {}
+        for training in (True, False):
+            prog = Program("D.spectral_norm")
+            for k, st in s.sn_state.items():
+                prog.add(ops.spectral_norm_fwd(st["W"], st["u_buf"], st["v_buf"], training, self.SN_EPS, st["sigma"], st["Wsn"], st["ws"]))
+                prog.add(lambda st=st: (st["u"].copy_(st["u_buf"]), st["v"].copy_(st["v_buf"])))
+            s.sn_fwd[training] = prog
+        s.repack = None
+
+    def _sn_bwd_program(self, s: _Slot) -> Program:
+        """dL/dweight_orig from dL/dW_sn (u, v, sigma as the slot's forward left them)."""
+        prog = Program("D.spectral_norm.bwd")
+        for k, st in s.sn_state.items():
+            prog.add(self.ctx.ops.spectral_norm_bwd(self.grads[k + ".weight"], st["Wsn"], st["u"], st["v"], st["sigma"],
+                                                    self.grads[k + ".weight_orig"], st["ws"]))
+        return prog
+
+    def _prepare_weights(self, s: _Slot):
+        """Operand copies current for this slot's next launches."""
+        if not self.sn:
+            self._sync_weights()
+            return
+        for k, p in zip(self.names, self.plist):
+            if p.data.data_ptr() != self.params[k].data_ptr():
+                raise RuntimeError(f"parameter {k} was re-allocated after the first forward (e.g. .to()/.half()): rebuild the module's bridge")
+        s.sn_fwd[bool(self.module.training)].run()
+        self._slot_repack(s)
+
+    def _slot_repack(self, s: _Slot):
+        if s.repack is None:
+            s.repack = Program("D.repack.slot")
+            for net in s.nets:
+                s.repack.add(net.repack_program())
+        s.repack.run()
+
+    def _passes(self, s: _Slot, B, H, W):
+        self._slot_weights(s)
         dps = []
-        for net in self.nets:
+        for net in s.nets:
             dps.append(net.new_pass(B, H, W))
             H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1       # AvgPool2d(3, 2, 1)
         return dps
@@ -295,7 +364,7 @@ class _DiscBridge(_Bridge):
     def _make_slot(self, B, H, W):
         ops, net = self.ctx.ops, self.net
         s = _Slot()
-        s.dps = self._passes(B, H, W)
+        s.dps = self._passes(s, B, H, W)
         s.xin = torch.zeros(B, net.in_c, H, W, dtype=torch.float32, device=self.device)
         s.fwd = Program("D.autograd.fwd")
         s.fwd.add(ops.nchw_to_view(s.xin, net.in_c, s.dps[0].x, HALO_ZERO))
@@ -316,7 +385,7 @@ class _DiscBridge(_Bridge):
         assert C == self.net.in_c
         s = self._lease((B, H, W), lambda: self._make_slot(B, H, W))
         try:
-            self._sync_weights()
+            self._prepare_weights(s)
             s.xin.copy_(x)
             s.fwd.run()
             outs = tuple(o.clone() for o in s.outs)
@@ -341,9 +410,15 @@ class _DiscBridge(_Bridge):
                 for i in range(len(s.dps) - 2, -1, -1):      # dL/dx_i += pool^T dL/dx_{i+1}
                     prog.add(ops.avgpool_bwd(s.dps[i + 1].g_input, s.dps[i].g_input, True))
                 prog.add(ops.view_to_nchw(s.dps[0].g_input, self.net.in_c, s.gx))
+            if need_w and self.sn:
+                prog.add(self._sn_bwd_program(s))
             s.bwd[key] = prog
-            self._repack, self._packed_version = None, None
-            self._sync_weights()
+            if self.sn:                      # planning the backward allocated operand copies: fill them from the slot's W_sn
+                s.repack = None
+                self._slot_repack(s)
+            else:
+                self._repack, self._packed_version = None, None
+                self._sync_weights()
         for dst, g in zip(s.g_outs, gs):
             dst.copy_(g)
         prog.run()
@@ -411,7 +486,7 @@ class _R1Fn(torch.autograd.Function):
         B, C, H, W = x.shape
         s = bridge._lease((B, H, W, "r1"), lambda: _r1_slot(bridge, B, H, W))
         try:
-            bridge._sync_weights()
+            bridge._prepare_weights(s)        # spectral norm: the R1 forward is a training-mode forward too (one more power iteration)
             s.xin.copy_(x)
             s.prog.run()
             loss = s.loss.clone().reshape(())
@@ -441,7 +516,7 @@ def _r1_slot(bridge: _DiscBridge, B, H, W) -> _Slot:
     folded back through the pools into g, and each scale's second-order half is seeded with g pooled down to its resolution."""
     ctx, ops, net = bridge.ctx, bridge.ctx.ops, bridge.net
     s = _Slot()
-    s.dps = bridge._passes(B, H, W)
+    s.dps = bridge._passes(s, B, H, W)
     s.xin = torch.zeros(B, net.in_c, H, W, dtype=torch.float32, device=bridge.device)
     s.loss = ctx.f32(1)
     s.scratch = ctx.f32(1)
@@ -460,6 +535,8 @@ def _r1_slot(bridge: _DiscBridge, B, H, W) -> _Slot:
         if i > 0:
             s.prog.add(ops.avgpool_fwd(us[i - 1], us[i]))
         s.prog.add(dp.r1_second(us[i]))
+    if bridge.sn:
+        s.prog.add(bridge._sn_bwd_program(s))
     return s
 
 

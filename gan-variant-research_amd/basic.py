@@ -57,18 +57,18 @@ class ResnetGenerator(nn.Module):
 
 
 class NLayerDiscriminator(nn.Module):
-    """Basic_GAN/src/models.py:71-107 (spectral norm off): keys net.{0,11}.{weight,bias}, net.{2,5,8}.weight."""
+    """Basic_GAN/src/models.py:71-107: keys net.{0,11}.{weight,bias}, net.{2,5,8}.weight -- with `spectral`, the three middle
+    convolutions carry weight_orig / weight_u / weight_v instead (models.py:67-69; normalisation by gan_spectral_norm_*, autograd.py)."""
 
     def __init__(self, in_c=3, ndf=64, n_layers=3, spectral=False):
         super().__init__()
-        if spectral:
-            raise NotImplementedError("spectral_norm_d is off in Basic_GAN/configs/baseline.yaml and not built on the MI355X path")
-        self.in_c, self.ndf, self.n_layers = in_c, ndf, n_layers
+        self.in_c, self.ndf, self.n_layers, self.spectral = in_c, ndf, n_layers, spectral
         seq = [nn.Conv2d(in_c, ndf, 4, stride=2, padding=1)] + _slots(1)
         mult = 1
         for n in range(1, n_layers + 1):
             prev, mult = mult, min(2**n, 8)
-            seq += [nn.Conv2d(ndf * prev, ndf * mult, 4, stride=2 if n < n_layers else 1, padding=1, bias=False)] + _slots(2)
+            conv = nn.Conv2d(ndf * prev, ndf * mult, 4, stride=2 if n < n_layers else 1, padding=1, bias=False)
+            seq += [nn.utils.spectral_norm(conv) if spectral else conv] + _slots(2)
         seq += [nn.Conv2d(ndf * mult, 1, 4, stride=1, padding=1)]
         self.net = nn.Sequential(*seq)
         self.compute_dtype = F32
@@ -112,6 +112,9 @@ class CycleGANTrainer:
     def __init__(self, G_A2B: ResnetGenerator, G_B2A: ResnetGenerator, D_A: NLayerDiscriminator, D_B: NLayerDiscriminator, cfg: dict,
                  batch_size: int, image_size: int, device="cuda", amp: Optional[bool] = None, ops=None, world_size: int = 1, process_group=None):
         self.cfg, self.B, self.S = cfg, batch_size, image_size
+        if getattr(D_A, "spectral", False) or getattr(D_B, "spectral", False):
+            raise NotImplementedError("the fused CycleGANTrainer runs Basic_GAN/configs/baseline.yaml (spectral_norm_d: false); "
+                                      "spectral-norm discriminators run through the nn.Module API (autograd.py)")
         self.device = torch.device(device)
         amp = cfg["training"].get("amp", True) if amp is None else amp
         self.dtype = BF16 if amp else F32

@@ -91,26 +91,31 @@ class ResNetGenerator(nn.Module):
 
 
 class _PatchGANParams(nn.Module):
-    def __init__(self, input_nc, ndf, n_layers):
+    def __init__(self, input_nc, ndf, n_layers, use_spectral_norm=False):
         super().__init__()
         chans = [input_nc, ndf] + [ndf * min(2**n, 8) for n in range(1, n_layers)] + [ndf * min(2**n_layers, 8), 1]
         seq = []
         for i in range(len(chans) - 1):
-            seq.append(nn.Conv2d(chans[i], chans[i + 1], 4, stride=2 if i < n_layers else 1, padding=1))
+            conv = nn.Conv2d(chans[i], chans[i + 1], 4, stride=2 if i < n_layers else 1, padding=1)
+            if use_spectral_norm:
+                # registration only (weight_orig / weight_u / weight_v, their initial draws and state_dict handling are torch's,
+                # discriminator_patchgan.py:21-23); the module's forward hook never runs here: the power iteration and the
+                # normalisation are gan_spectral_norm_fwd / _bwd (autograd.py)
+                conv = nn.utils.spectral_norm(conv)
+            seq.append(conv)
             if i < len(chans) - 2:
                 seq.append(nn.Identity())
         self.model = nn.Sequential(*seq)
 
 
 class MultiscaleDiscriminator(nn.Module):
-    """Signature of models/discriminator_patchgan.py:81-88; the baseline config is one scale, no spectral norm."""
+    """Signature and defaults of models/discriminator_patchgan.py:81-88.  The baseline config (one scale, no spectral norm) is what the
+    fused CutTrainer runs; more scales and spectral norm run through this module API (autograd.py)."""
 
     def __init__(self, input_nc=3, ndf=64, n_layers=3, num_scales=3, use_spectral_norm=True):
         super().__init__()
-        if use_spectral_norm:
-            raise NotImplementedError("use_spectral_norm=True is not built on the MI355X path (off in configs/train_gan_cutpp.yaml)")
-        self.input_nc, self.ndf, self.n_layers, self.num_scales = input_nc, ndf, n_layers, num_scales
-        self.discriminators = nn.ModuleList([_PatchGANParams(input_nc, ndf, n_layers) for _ in range(num_scales)])
+        self.input_nc, self.ndf, self.n_layers, self.num_scales, self.use_spectral_norm = input_nc, ndf, n_layers, num_scales, use_spectral_norm
+        self.discriminators = nn.ModuleList([_PatchGANParams(input_nc, ndf, n_layers, use_spectral_norm) for _ in range(num_scales)])
         self.compute_dtype = F32
 
     def forward(self, x):

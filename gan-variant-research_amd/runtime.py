@@ -346,6 +346,25 @@ class HipOps:
     def view_copy(self, src: View, dst: View, halo_mode) -> Op:
         return self._call("gan_view_copy", self._v(src), self._v(dst), halo_mode, self._s())
 
+    def spectral_norm_ws_floats(self, h, w) -> int:
+        return int(_lib.load().gan_spectral_norm_ws_floats(h, w))
+
+    def spectral_norm_fwd(self, W, u, v, power_iter: bool, eps, sigma, Wsn, ws) -> Op:
+        h, w = W.shape[0], W.numel() // W.shape[0]
+        for t in (W, u, v, sigma, Wsn, ws):
+            assert t.dtype == torch.float32 and t.is_contiguous()
+        assert u.numel() == h and v.numel() == w and Wsn.numel() == W.numel() and ws.numel() >= self.spectral_norm_ws_floats(h, w)
+        return self._call("gan_spectral_norm_fwd", self._p(W), h, w, self._p(u), self._p(v), int(power_iter), float(eps), self._p(sigma),
+                          self._p(Wsn), self._p(ws), self._s())
+
+    def spectral_norm_bwd(self, G, Wsn, u, v, sigma, dW, ws) -> Op:
+        h, w = G.shape[0], G.numel() // G.shape[0]
+        for t in (G, Wsn, u, v, sigma, dW, ws):
+            assert t.dtype == torch.float32 and t.is_contiguous()
+        assert u.numel() == h and v.numel() == w and dW.numel() == G.numel() and ws.numel() >= self.spectral_norm_ws_floats(h, w)
+        return self._call("gan_spectral_norm_bwd", self._p(G), self._p(Wsn), self._p(u), self._p(v), self._p(sigma), h, w, self._p(dW),
+                          self._p(ws), self._s())
+
     def avgpool_fwd(self, x: View, y: View) -> Op:
         return self._call("gan_avgpool_fwd", self._v(x), self._v(y), self._s())
 

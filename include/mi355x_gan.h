@@ -154,6 +154,18 @@ int gan_view_copy(const gan_view* src, const gan_view* dst, int halo_mode, void*
 int gan_avgpool_fwd(const gan_view* x, const gan_view* y, void* stream);
 int gan_avgpool_bwd(const gan_view* gy, const gan_view* gx, int accumulate, void* stream);
 
+/* ---- Spectral normalisation of a convolution weight: torch.nn.utils.spectral_norm as applied by
+ *      GAN_Variant1/models/discriminator_patchgan.py:21-23 and Basic_GAN/src/models.py:68-69 (n_power_iterations 1, eps 1e-12).
+ *      W = weight_orig as an h x w row-major matrix (h = Cout, w = Cin*kh*kw: the OIHW tensor itself); u [h], v [w] are the
+ *      module's weight_u / weight_v buffers.  fwd: if power_iter, v <- normalize(W^T u), u <- normalize(W v) in place; then
+ *      *sigma = u . (W v) and Wsn = W / sigma.  bwd: dW = (G - <G, Wsn> u v^T) / sigma with G = dL/dWsn (u, v, sigma: the values
+ *      the forward left).  ws: fp32, >= gan_spectral_norm_ws_floats(h, w). */
+int64_t gan_spectral_norm_ws_floats(int h, int w);
+int gan_spectral_norm_fwd(const float* W, int h, int w, float* u, float* v, int power_iter, float eps, float* sigma, float* Wsn,
+                          float* ws, void* stream);
+int gan_spectral_norm_bwd(const float* G, const float* Wsn, const float* u, const float* v, const float* sigma, int h, int w,
+                          float* dW, float* ws, void* stream);
+
 /* ---- DiffAugment (GAN_Variant1/training/diffaugment.py:6-60,94-106), per-sample parameters injected.
  *      prm = device fp32 [B][12]: brightness add, saturation factor, contrast factor, tx, ty,
  *      cut_lo_h, cut_hi_h, cut_lo_w, cut_hi_w (inclusive; lo>hi = no cutout), 3 spare.  C = real channels (3). */

@@ -266,6 +266,53 @@ def gen_optional(tc):
     record("ms3", MultiscaleDiscriminator(3, 4, 3, num_scales=3, use_spectral_norm=False), 1)
     set_seed(6)
     record("sn2", MultiscaleDiscriminator(3, 4, 3, num_scales=2, use_spectral_norm=True), 2)
+    # the real train_step with the constructor-default discriminator family: two scales, spectral norm (every D forward of the
+    # step -- D(real), D(fake), the R1 forward, the G-step's D(fake) -- advances the power iteration)
+    from GAN_Variant1.training.diffaugment import DiffAugment
+    from GAN_Variant1.training.sched_optim import get_optimizer
+    from GAN_Variant1.utils.io_ckpt import EMA
+    cfg = _cfg(tc)
+    cfg["model"]["discriminator"]["num_scales"] = 2
+    cfg["model"]["discriminator"]["use_spectral_norm"] = True
+    torch.set_num_threads(1)
+    set_seed(42)
+    G, D = tc.build_models(cfg, "cpu")
+    opt_G, opt_D = get_optimizer(G, cfg["optim"]["G"]), get_optimizer(D, cfg["optim"]["D"])
+    ema = EMA(G, cfg["ema"]["decay"])
+    aug = DiffAugment(cfg["diffaugment"]["policy"])
+    photos, monets = _inputs(2, 64)
+    for step in range(2):
+        torch.manual_seed(9000 + step)
+        losses = tc.train_step(step, photos.clone(), monets.clone(), G, D, opt_G, opt_D, ema, amp, aug, cfg, "cpu")
+        for k, v in losses.items():
+            out[f"step_sn2.step{step}.{k}"] = torch.tensor(v, dtype=torch.float64)
+    out["step_sn2.u_after"] = D.state_dict()["discriminators.1.model.6.weight_u"].clone()
+    torch.set_num_threads(8)
+
+    # Basic_GAN: spectral norm on the three bias-free middle convolutions only (Basic_GAN/src/models.py:67-69, 87-101)
+    from src.losses import GANLoss
+    from src.models import NLayerDiscriminator
+    torch.manual_seed(7)
+    Db = NLayerDiscriminator(3, 4, 3, spectral=True)
+    for k, v in Db.state_dict().items():
+        out[f"bsn.sd.{k}"] = v.clone()
+    xs = x[:, :, :64, :64].clone().requires_grad_(True)
+    Db(x[:, :, :64, :64])
+    o = Db(xs)
+    out["bsn.out"] = o.detach().clone()
+    loss = GANLoss("lsgan")(o, True) + 0.5 * GANLoss("lsgan")(Db(y[:, :, :64, :64]), False)
+    out["bsn.loss"] = loss.detach()
+    names = [k for k, _ in Db.named_parameters()]
+    grads = torch.autograd.grad(loss, [xs] + [p for _, p in Db.named_parameters()])
+    out["bsn.gx"] = grads[0]
+    for k, gr in zip(names, grads[1:]):
+        out[f"bsn.gw.{k}"] = gr
+    for k, v in Db.state_dict().items():
+        if k.endswith("_u") or k.endswith("_v"):
+            out[f"bsn.sd_after.{k}"] = v.clone()
+    Db.eval()
+    with torch.no_grad():
+        out["bsn.eval_out"] = Db(x[:, :, :64, :64]).clone()
     np.savez_compressed(os.path.join(OUT, "cut_optional.npz"), **_np(out))
 
 

@@ -346,6 +346,25 @@ class EmuOps:
                 _store(dst, v)
         return op
 
+    def spectral_norm_ws_floats(self, h, w):
+        return h + w + 272
+
+    def spectral_norm_fwd(self, W, u, v, power_iter, eps, sigma, Wsn, ws):
+        def op():
+            m = W.reshape(W.shape[0], -1)
+            if power_iter:
+                v.copy_(F.normalize(torch.mv(m.t(), u), dim=0, eps=eps))
+                u.copy_(F.normalize(torch.mv(m, v), dim=0, eps=eps))
+            sigma.fill_(float(torch.dot(u, torch.mv(m, v))))
+            Wsn.copy_(W / sigma)
+        return op
+
+    def spectral_norm_bwd(self, G, Wsn, u, v, sigma, dW, ws):
+        def op():
+            dot = (G * Wsn).sum()
+            dW.copy_((G.reshape(G.shape[0], -1) - dot * torch.outer(u, v)).reshape(G.shape) / sigma)
+        return op
+
     def avgpool_fwd(self, x, y):
         def op():
             v = x.nhwc().float().permute(0, 3, 1, 2)

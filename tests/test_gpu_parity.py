@@ -162,6 +162,28 @@ def test_layout_and_losses_twins(dtype):
     tw.check(*([1e-4, 1e-5] if dtype == F32 else [2e-2, 2e-2]))
 
 
+@pytest.mark.parametrize("shape", [(512, 256, 4), (64, 3, 4), (1, 512, 4), (37, 5, 3)])
+def test_spectral_norm_twins(shape):
+    """gan_spectral_norm_fwd (training: one power iteration in place; eval: sigma from the stored u, v) and _bwd against the
+    torch formulas of torch.nn.utils.spectral_norm (tests/emulator.py), at the largest discriminator weight (512 x 4096)."""
+    cout, cin, k = shape
+    tw = Twin(F32)
+    Wc, Wg = tw.f32(torch.randn(cout, cin, k, k, generator=tw.gen) * 0.05)
+    h, w = cout, cin * k * k
+    uc, ug = tw.f32(torch.nn.functional.normalize(torch.randn(h, generator=tw.gen), dim=0))
+    vc, vg = tw.f32(torch.nn.functional.normalize(torch.randn(w, generator=tw.gen), dim=0))
+    sc, sg = tw.f32(torch.zeros(1))
+    nc, ng = tw.f32(torch.zeros(cout, cin, k, k))
+    n = tw.c.ops.spectral_norm_ws_floats(h, w)
+    wsc, wsg = torch.zeros(n), torch.zeros(tw.g.ops.spectral_norm_ws_floats(h, w), device=DEV)
+    for train in (True, True, False):
+        tw.run(tw.c.ops.spectral_norm_fwd(Wc, uc, vc, train, 1e-12, sc, nc, wsc), tw.g.ops.spectral_norm_fwd(Wg, ug, vg, train, 1e-12, sg, ng, wsg))
+    Gc, Gg = tw.f32(torch.randn(cout, cin, k, k, generator=tw.gen))
+    dc, dg = tw.f32(torch.zeros(cout, cin, k, k))
+    tw.run(tw.c.ops.spectral_norm_bwd(Gc, nc, uc, vc, sc, dc, wsc), tw.g.ops.spectral_norm_bwd(Gg, ng, ug, vg, sg, dg, wsg))
+    tw.check(2e-4, 2e-5)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("hw", [(24, 24), (25, 31), (7, 2), (1, 1)])
 def test_avgpool_twins(hw, dtype):
@@ -270,12 +292,14 @@ def test_autograd_bridge_hip():
     bridge_cases(DEV, 5e-4)
 
 
-def test_multiscale_discriminator_hip(monkeypatch):
-    """MultiscaleDiscriminator(num_scales=3) -- outputs, gradients, R1 through the pooled scales -- vs vectors produced by the reference."""
+@pytest.mark.parametrize("tag", ["ms3", "sn2", "bsn"])
+def test_optional_discriminators_hip(monkeypatch, tag):
+    """MultiscaleDiscriminator with num_scales=3 (ms3) and with spectral norm over two scales (sn2) -- outputs, gradients, the power
+    iteration's buffers, R1 through the pooled scales, eval mode -- against vectors produced by the reference itself."""
     from gan_variant_research_amd import losses as L
     from tests.test_autograd_bridge import optional_cases
     monkeypatch.setattr(L, "_PLANS", {})
-    optional_cases(torch.device(DEV), 5e-4, tags=("ms3",))
+    optional_cases(torch.device(DEV), 5e-4, tags=(tag,))
 
 
 def test_loss_callables_hip(monkeypatch):
@@ -288,6 +312,14 @@ def test_loss_callables_hip(monkeypatch):
 def test_training_utilities_hip(tmp_path):
     from tests.test_autograd_bridge import training_cases
     training_cases(DEV, 1e-5, tmp_path)
+
+
+def test_module_step_default_discriminator_family_hip(monkeypatch):
+    """module_step.train_step with a two-scale spectral-norm discriminator vs the reference's own train_step (golden), steps 0-1."""
+    from gan_variant_research_amd import losses as L
+    from tests.test_autograd_bridge import optional_step_cases
+    monkeypatch.setattr(L, "_PLANS", {})
+    optional_step_cases(torch.device(DEV), 1e-3, 2e-3)
 
 
 def test_module_step_hip(monkeypatch):
