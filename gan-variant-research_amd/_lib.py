@@ -48,6 +48,12 @@ class GanPackDesc(C.Structure):
                 ("swap", i32), ("I2", i32), ("KK", i32), ("layout", i32), ("first_block", i32), ("nblocks", i32)]
 
 
+class GanInputJob(C.Structure):
+    _fields_ = [("src", vp), ("src_stride", i32), ("crop_y", i32), ("crop_x", i32), ("crop_h", i32), ("crop_w", i32), ("res_h", i32), ("res_w", i32),
+                ("win_y", i32), ("win_x", i32), ("flip", i32), ("order", i32 * 4), ("factor", f32 * 4), ("hue_shift", i32),
+                ("hb_off", i32), ("hk_off", i32), ("hksize", i32), ("vb_off", i32), ("vk_off", i32), ("vksize", i32)]
+
+
 PV, PC, PW = C.POINTER(GanView), C.POINTER(GanConvDesc), C.POINTER(GanWgradDesc)
 
 # name -> (restype, argtypes); must list every function of include/mi355x_gan.h
@@ -75,6 +81,9 @@ PROTOTYPES = {
     "gan_view_to_nchw": (C.c_int, [PV, C.c_int, vp, vp]),
     "gan_view_copy": (C.c_int, [PV, PV, C.c_int, vp]),
     "gan_avgpool_fwd": (C.c_int, [PV, PV, vp]),
+    "gan_resize_ksize": (C.c_int, [C.c_int, C.c_int]),
+    "gan_resize_coeffs": (C.c_int, [C.c_int, C.c_int, vp, vp, C.c_int]),
+    "gan_input_pipeline": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]),
     "gan_spectral_norm_ws_floats": (C.c_int64, [C.c_int, C.c_int]),
     "gan_spectral_norm_fwd": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_float, vp, vp, vp, vp]),
     "gan_spectral_norm_bwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]),

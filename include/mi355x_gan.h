@@ -172,6 +172,32 @@ int gan_spectral_norm_bwd(const float* G, const float* Wsn, const float* u, cons
 int gan_diffaug_fwd(const gan_view* x, int C, const float* prm, const gan_view* y, float* ws, void* stream);
 int gan_diffaug_bwd(const gan_view* gy, int C, const float* prm, const gan_view* gx, float* ws, void* stream);
 
+/* ---- Device-side input pipeline: what the reference's dataset workers do per image with PIL, bit for bit --
+ *      GAN_Variant1/dataio/transforms.py:10-49 (RandomCropResize = crop + BICUBIC resize, RandomHorizontalFlip,
+ *      ColorJitter(0.05,0.05,0.05,0.02), ToTensor, Normalize(0.5,0.5); eval: Resize) and Basic_GAN/src/data.py:8-26
+ *      (Resize(load_size, BICUBIC), RandomCrop/CenterCrop, flip, ToTensor, Normalize).  One job per image; the random draws are
+ *      made by the caller (dataio.py reproduces the reference's draw order) so the kernels are deterministic. */
+typedef struct gan_input_job {
+  const uint8_t* src;            /* device: decoded RGB, HWC, 3 bytes per pixel */
+  int32_t src_stride;            /* bytes per source row */
+  int32_t crop_y, crop_x, crop_h, crop_w;   /* TF.crop box in the source (whole image: 0,0,H,W) */
+  int32_t res_h, res_w;          /* size the box is resized to (Image.resize, BICUBIC) */
+  int32_t win_y, win_x;          /* S x S window taken from the resized image (RandomCrop / CenterCrop; 0,0 when res == S) */
+  int32_t flip;                  /* RandomHorizontalFlip */
+  int32_t order[4];              /* ColorJitter: op applied in slot 0..3 (0 brightness, 1 contrast, 2 saturation, 3 hue, -1 none) */
+  float factor[4];               /* brightness, contrast, saturation factors (indexed by op); [3] unused */
+  int32_t hue_shift;             /* uint8(hue_factor * 255): added to the H channel with wrap-around */
+  int32_t hb_off, hk_off, hksize;  /* horizontal taps in the tables block (int32 units): bounds [res_w][2], taps [res_w][hksize] */
+  int32_t vb_off, vk_off, vksize;  /* vertical taps: bounds [res_h][2], taps [res_h][vksize] */
+} gan_input_job;
+/* Pillow's bicubic taps for resizing in_size -> out_size (Resample.c precompute_coeffs, 22-bit fixed point).  Host-only, no GPU. */
+int gan_resize_ksize(int in_size, int out_size);
+int gan_resize_coeffs(int in_size, int out_size, int32_t* bounds /* [out][2]: first index, count */, int32_t* kk /* [out][ksize] */, int ksize);
+/* jobs_dev/tables_dev: device copies; jobs_host: the same jobs readable by the host (validation, launch shapes).
+ * tmp: >= B*tmp_rows*S*4 bytes (tmp_rows >= max crop_h); img: B*S*S*4 bytes; mean_ws: B int32; out: fp32 [B][3][S][S] in [-1,1]. */
+int gan_input_pipeline(const gan_input_job* jobs_dev, const gan_input_job* jobs_host, int B, const int32_t* tables_dev, int S,
+                       uint8_t* tmp, int tmp_rows, uint8_t* img, int32_t* mean_ws, float* out, void* stream);
+
 /* ---- losses.  Every loss writes its value to *loss (device fp32, overwritten) and the gradient wrt its input.
  *      hinge: adv_hinge.py:6-62 (mode 0: mean relu(1-x), 1: mean relu(1+x), 2: -mean x), scaled by `scale`;
  *      lsgan/bce: Basic_GAN/src/losses.py:5-22 (mode 3: mse vs target, 4: bce-with-logits vs target in {0,1});

@@ -316,9 +316,34 @@ def gen_optional(tc):
     np.savez_compressed(os.path.join(OUT, "cut_optional.npz"), **_np(out))
 
 
+def gen_input():
+    """Input-pipeline fixture: small images through the reference's transform chains, executed by Pillow (the library behind the
+    reference's torchvision transforms; torchvision itself is absent here) -- oracle/input_ref.py:apply_pil."""
+    from oracle import input_ref as R
+    rng = np.random.default_rng(2024)
+    cases = [((40, 52), {"crop": (3, 9, 36, 36), "resize": (32, 32), "window": (0, 0, 32, 32), "flip": True, "order": (2, 0, 3, 1), "factor": (1.0313, 0.9622, 1.0455, -0.0173)}),
+             ((33, 33), {"crop": (0, 0, 33, 33), "resize": (32, 32), "window": (0, 0, 32, 32), "flip": False, "order": (-1, -1, -1, -1), "factor": (1.0, 1.0, 1.0, 0.0)}),
+             ((48, 64), {"crop": (0, 0, 48, 64), "resize": (36, 48), "window": (2, 11, 32, 32), "flip": True, "order": (-1, -1, -1, -1), "factor": (1.0, 1.0, 1.0, 0.0)}),
+             ((64, 64), {"crop": (5, 2, 58, 58), "resize": (32, 32), "window": (0, 0, 32, 32), "flip": False, "order": (3, 1, 0, 2), "factor": (0.9507, 1.0499, 0.9731, 0.0199)})]
+    out = {"n": np.asarray(len(cases))}
+    for i, ((h, w), job) in enumerate(cases):
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.clip(np.stack([127 + 110 * np.sin(yy / 7.0 + c) * np.cos(xx / 9.0 - c) for c in range(3)], -1) + rng.integers(-25, 26, (h, w, 3)), 0, 255).astype(np.uint8)
+        out[f"{i}.image"] = img
+        for k, v in job.items():
+            out[f"{i}.{k}"] = np.asarray(v)
+        out[f"{i}.out"] = R.apply_pil(img, job)
+    np.savez_compressed(os.path.join(OUT, "input_pipeline.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "input":
+        gen_input()
+        print("input_pipeline.npz", os.path.getsize(os.path.join(OUT, "input_pipeline.npz")))
+        return
     tc = _import_reference()
+    gen_input()
     if len(sys.argv) > 1 and sys.argv[1] == "optional":
         gen_optional(tc)
         print("cut_optional.npz", os.path.getsize(os.path.join(OUT, "cut_optional.npz")))
