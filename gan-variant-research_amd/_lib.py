@@ -48,6 +48,10 @@ class GanPackDesc(C.Structure):
                 ("swap", i32), ("I2", i32), ("KK", i32), ("layout", i32), ("first_block", i32), ("nblocks", i32)]
 
 
+class GanBiasPartDesc(C.Structure):
+    _fields_ = [("part", vp), ("grad", vp), ("nparts", i32), ("C", i32), ("N_real", i32), ("accumulate", i32), ("first_block", i32), ("_pad", i32)]
+
+
 class GanInputJob(C.Structure):
     _fields_ = [("src", vp), ("src_stride", i32), ("crop_y", i32), ("crop_x", i32), ("crop_h", i32), ("crop_w", i32), ("res_h", i32), ("res_w", i32),
                 ("win_y", i32), ("win_x", i32), ("flip", i32), ("order", i32 * 4), ("factor", f32 * 4), ("hue_shift", i32),
@@ -81,6 +85,9 @@ PROTOTYPES = {
     "gan_view_to_nchw": (C.c_int, [PV, C.c_int, vp, vp]),
     "gan_view_copy": (C.c_int, [PV, PV, C.c_int, vp]),
     "gan_avgpool_fwd": (C.c_int, [PV, PV, vp]),
+    "gan_in_bwd_bias_parts": (C.c_int, [PV]),
+    "gan_in_bwd_bias_deferred": (C.c_int, [PV, vp, C.c_int, PV, C.c_int, PV, PV, vp, vp, vp]),
+    "gan_bias_finalize_batch": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "gan_resize_ksize": (C.c_int, [C.c_int, C.c_int]),
     "gan_resize_coeffs": (C.c_int, [C.c_int, C.c_int, vp, vp, C.c_int]),
     "gan_input_pipeline": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]),

@@ -323,6 +323,27 @@ __global__ __launch_bounds__(256) void bias_part_finalize_kernel(const float* __
   }
 }
 
+// the same sum for many layers in ONE launch: block -> (descriptor, 32-channel group) through first_block
+__global__ __launch_bounds__(256) void bias_finalize_batch_kernel(const gan_bias_part_desc* __restrict__ descs, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const gan_bias_part_desc d = descs[lo];
+  const int c = ((int)blockIdx.x - d.first_block) * 32 + (threadIdx.x & 31), k0 = threadIdx.x >> 5;
+  float s = 0.f;
+  if (c < d.C)
+    for (int k = k0; k < d.nparts; k += 8) s += d.part[(int64_t)k * d.C + c];
+  __shared__ float sh[256];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (k0 == 0 && c < d.N_real) {
+    for (int k = 1; k < 8; ++k) s += sh[k * 32 + (threadIdx.x & 31)];
+    d.grad[c] = d.accumulate ? d.grad[c] + s : s;
+  }
+}
+
 // out = a + fold(b)   /   dx = (fold(g) + g2) * act'(y)
 template <typename T>
 __global__ __launch_bounds__(NTHR) void fold_add_kernel(DView a, int has_a, DView g, int fold, DView y, int act, DView out, int nblk) {
@@ -509,7 +530,7 @@ extern "C" int gan_in_apply(const gan_view* x, const float* stats, int act, cons
 
 // ws: fp32, >= B*MAXCH*C*2 + B*C*2 floats
 static int in_bwd_impl(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2, const gan_view* dx,
-                       float* ws, float* bias_grad, int bias_n, int bias_acc, void* stream);
+                       float* ws, float* bias_grad, int bias_n, int bias_acc, void* stream, float* bias_part = nullptr);
 
 extern "C" int gan_in_bwd(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2,
                           const gan_view* dx, float* ws, void* stream) {
@@ -525,7 +546,7 @@ extern "C" int gan_in_bwd_bias(const gan_view* x, const float* stats, int act, c
 }
 
 static int in_bwd_impl(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2, const gan_view* dx,
-                       float* ws, float* bias_grad, int bias_n, int bias_acc, void* stream) {
+                       float* ws, float* bias_grad, int bias_n, int bias_acc, void* stream, float* bias_part) {
   VCHK(x, "in_bwd.x"); VCHK(gy, "in_bwd.gy"); VCHK(dx, "in_bwd.dx");
   if (check_lanes(x, "in_bwd")) return -1;
   SAME_SHAPE(x, gy, "in_bwd(x,gy)"); SAME_SHAPE(x, dx, "in_bwd(x,dx)");
@@ -542,8 +563,8 @@ static int in_bwd_impl(const gan_view* x, const float* stats, int act, const gan
     hipLaunchKernelGGL((in_bwd_partial_kernel<T>), dim3(nch, x->B), dim3(NTHR), 0, s, vx, stats, act, vg, fold, v2, g2 ? 1 : 0, nch, ws);
     hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3((BC + 31) / 32), dim3(256), 0, s, ws, nch, x->C, BC, HW, ws2);
     hipLaunchKernelGGL((in_bwd_apply_kernel<T>), dim3(nblk, x->B), dim3(NTHR), 0, s, vx, stats, act, vg, fold, v2, g2 ? 1 : 0, ws2, vd, nblk,
-                       bias_grad ? ws2 + (int64_t)BC * 2 : nullptr);)
-  if (bias_grad) {
+                       bias_part ? bias_part : (bias_grad ? ws2 + (int64_t)BC * 2 : nullptr));)
+  if (bias_grad && !bias_part) {
     float* part = ws2 + (int64_t)BC * 2;
     const int nparts = x->B * nblk;
     if (nparts > 64) {   // two levels: 32 segments -> scratch behind the partials, then the final 32 -> grad
@@ -554,6 +575,26 @@ static int in_bwd_impl(const gan_view* x, const float* stats, int act, const gan
       hipLaunchKernelGGL(bias_part_finalize_kernel, dim3((x->C + 31) / 32, 1), dim3(256), 0, s, part, nparts, x->C, bias_n, bias_grad, 0, bias_acc);
     }
   }
+  GAN_LAUNCH_CHECK();
+  return 0;
+}
+
+// The bias-gradient partials of gan_in_bwd_bias go to a caller-owned buffer ([gan_in_bwd_bias_parts(x)][x->C] floats) and are summed
+// later, for all layers of a backward pass at once, by gan_bias_finalize_batch: two tiny launches per layer leave the backward chain.
+extern "C" int gan_in_bwd_bias_parts(const gan_view* x) {
+  if (gan_check_view(x, "in_bwd_bias_parts.x")) return -1;
+  return x->B * nblocks_for(x->H * x->W, lanes_of(x));
+}
+
+extern "C" int gan_in_bwd_bias_deferred(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2,
+                                        const gan_view* dx, float* ws, float* bias_part, void* stream) {
+  GAN_CHECK(bias_part, "in_bwd_bias_deferred: null partial buffer");
+  return in_bwd_impl(x, stats, act, gy, fold, g2, dx, ws, nullptr, 0, 0, stream, bias_part);
+}
+
+extern "C" int gan_bias_finalize_batch(const gan_bias_part_desc* descs, int n, int total_blocks, void* stream) {
+  GAN_CHECK(descs && n > 0 && total_blocks > 0, "bias_finalize_batch: empty batch");
+  hipLaunchKernelGGL(bias_finalize_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs, n);
   GAN_LAUNCH_CHECK();
   return 0;
 }

@@ -8,6 +8,8 @@ add + padding are one pass, and gradients of reflection padding are folded by th
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
@@ -209,9 +211,23 @@ class GPass:
             if ev is not None:
                 prog.add(ops.wait(ev))
 
+        # bias gradients in front of a norm are column sums of dx: the norm backward leaves per-block partials in a buffer of the
+        # layer's own and ONE launch at the end of the program sums them for every layer (two tiny launches per layer less on the chain)
+        defer = os.environ.get("GAN_BIAS_DEFER", "1") != "0"
+        bias_items = []
+        if not hasattr(self, "_bias_parts"):
+            self._bias_parts = {}
+
         def inbwd(raw, stats, act, gy, fold, dx, conv=None):
             """InstanceNorm backward; with `conv`, its bias gradient (column sums of dx) comes out of the same pass."""
-            if conv is not None and conv.grad_b is not None:
+            if conv is not None and conv.grad_b is not None and defer:
+                nparts = ops.in_bwd_bias_parts(raw)
+                part = self._bias_parts.get(id(conv))
+                if part is None:
+                    part = self._bias_parts[id(conv)] = ctx.f32(nparts * raw.C)
+                prog.add(ops.in_bwd_bias_deferred(raw, stats, act, gy, fold, None, dx, net.in_ws(B, raw.C), part))
+                bias_items.append((part, nparts, raw.C, conv.grad_b, conv.cout, acc))
+            elif conv is not None and conv.grad_b is not None:
                 prog.add(ops.in_bwd_bias(raw, stats, act, gy, fold, None, dx, net.in_ws(B, raw.C), conv.grad_b, conv.cout, acc))
             else:
                 prog.add(ops.in_bwd(raw, stats, act, gy, fold, None, dx, net.in_ws(B, raw.C)))
@@ -285,6 +301,8 @@ class GPass:
         if need_input_grad:
             self.g_input = net.gbuf("g_x0", B, H, W, self.x0.C, 3)   # padded domain: consumer folds
             prog.add(net.c_init.dgrad(dy0, self.g_input, padded_domain=True))
+        if bias_items:
+            prog.add(ops.bias_finalize_batch(bias_items))
         join = ops.new_event()       # everything after this program (next pass, all-reduce, optimiser) sees complete gradients
         prog.add(side.record(join))
         prog.add(ops.wait(join))

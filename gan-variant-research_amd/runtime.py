@@ -329,6 +329,28 @@ class HipOps:
         return self._call("gan_in_bwd_bias", self._v(x), self._p(stats), act, self._v(gy), int(fold), self._v(g2), self._v(dx), self._p(ws),
                           self._p(bias_grad), bias_n, int(accumulate), self._s())
 
+    def in_bwd_bias_parts(self, x: View) -> int:
+        n = int(self.lib.gan_in_bwd_bias_parts(self._v(x)))
+        if n < 0:
+            raise _lib.GanError(self.lib.gan_last_error().decode())
+        return n
+
+    def in_bwd_bias_deferred(self, x: View, stats, act, gy: View, fold, g2: Optional[View], dx: View, ws, bias_part) -> Op:
+        assert bias_part.dtype == torch.float32 and bias_part.numel() >= self.in_bwd_bias_parts(x) * x.C
+        return self._call("gan_in_bwd_bias_deferred", self._v(x), self._p(stats), act, self._v(gy), int(fold), self._v(g2), self._v(dx), self._p(ws),
+                          self._p(bias_part), self._s())
+
+    def bias_finalize_batch(self, items) -> Op:
+        """items: (part, nparts, C, grad, N_real, accumulate) per layer -> one launch."""
+        arr = (_lib.GanBiasPartDesc * len(items))()
+        first = 0
+        for d, (part, nparts, Cc, grad, n_real, acc) in zip(arr, items):
+            self._keep.extend((part, grad))
+            d.part, d.grad, d.nparts, d.C, d.N_real, d.accumulate = part.data_ptr(), grad.data_ptr(), nparts, Cc, n_real, int(acc)
+            d.first_block, first = first, first + (Cc + 31) // 32
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        return self._call("gan_bias_finalize_batch", self._p(table), len(items), first, self._s())
+
     def fold_add(self, a: Optional[View], b: View, fold, out: View) -> Op:
         return self._call("gan_fold_add", self._v(a), self._v(b), int(fold), self._v(out), self._s())
 

@@ -139,6 +139,17 @@ int gan_in_bwd(const gan_view* x, const float* stats, int act, const gan_view* g
 int gan_in_bwd_bias(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2,
                     const gan_view* dx, float* ws, float* bias_grad, int bias_n, int bias_accumulate, void* stream);
 /* out = a + fold(b): gradient of a residual block input (skip path + reflect-padded conv path) */
+/* gan_in_bwd_bias with the bias-gradient sum deferred: the per-block column sums go to `bias_part`
+ * ([gan_in_bwd_bias_parts(x)][x->C] floats, caller-owned) and gan_bias_finalize_batch adds them up for many layers in one launch
+ * (descs on the device; first_block = running sum of ceil(C/32); total_blocks = that sum over all descriptors). */
+typedef struct gan_bias_part_desc {
+  const float* part; float* grad;
+  int32_t nparts, C, N_real, accumulate, first_block, _pad;
+} gan_bias_part_desc;
+int gan_in_bwd_bias_parts(const gan_view* x);
+int gan_in_bwd_bias_deferred(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2,
+                             const gan_view* dx, float* ws, float* bias_part, void* stream);
+int gan_bias_finalize_batch(const gan_bias_part_desc* descs, int n, int total_blocks, void* stream);
 int gan_fold_add(const gan_view* a, const gan_view* b, int fold, const gan_view* out, void* stream);
 /* dx = g * act'(y) (tanh: 1-y^2, lrelu: y>0?1:0.2), g optionally folded; written to the interior of dx */
 int gan_act_bwd(const gan_view* y, int act, const gan_view* g, int fold, const gan_view* g2, const gan_view* dx, void* stream);

@@ -300,6 +300,24 @@ class EmuOps:
             bias_grad.copy_(bias_grad + s if accumulate else s)
         return op
 
+    def in_bwd_bias_parts(self, x):
+        return x.B
+
+    def in_bwd_bias_deferred(self, x, stats, act, gy, fold, g2, dx, ws, bias_part):
+        inner = self.in_bwd(x, stats, act, gy, fold, g2, dx, ws)
+
+        def op():
+            inner()
+            bias_part[:x.B * x.C].view(x.B, x.C).copy_(dx.nhwc().float().sum((1, 2)))
+        return op
+
+    def bias_finalize_batch(self, items):
+        def op():
+            for part, nparts, Cc, grad, n_real, acc in items:
+                s = part[:nparts * Cc].view(nparts, Cc).sum(0)[:n_real]
+                grad.copy_(grad + s if acc else s)
+        return op
+
     def fold_add(self, a, b, fold, out):
         def op():
             v = _fold(b, fold)

@@ -114,6 +114,21 @@ def test_instance_norm_twins(shape, dtype):
         np.testing.assert_allclose(bg.cpu().numpy(), bc.numpy(), rtol=TOL[dtype][0] * 5, atol=TOL[dtype][1] * 5 * (B * H * W) ** 0.5)
         tw.tensors.pop()   # bias compared above with a magnitude-aware tolerance
         tw.check(TOL[dtype][0] * 5, TOL[dtype][1] * 5)
+        # the deferred variant: partials to a caller-owned buffer, one batched launch sums them (two layers share the launch):
+        # bit-identical on the GPU to nothing but itself, so it is compared with the immediate variant's result on the same dx
+        npc, npg = tw.c.ops.in_bwd_bias_parts(xc), tw.g.ops.in_bwd_bias_parts(xg)
+        pc, pg = torch.zeros(npc * C), torch.zeros(npg * C, device=DEV)
+        p2c, p2g = torch.zeros(npc * C), torch.zeros(npg * C, device=DEV)
+        b1c, b1g = torch.zeros(nb), torch.zeros(nb, device=DEV)
+        b2c, b2g = torch.ones(nb), torch.ones(nb, device=DEV)
+        tw.run([tw.c.ops.in_bwd_bias_deferred(xc, sc, act, gc, bool(fold), g2c, dc, w2c, pc), tw.c.ops.in_bwd_bias_deferred(xc, sc, act, gc, bool(fold), g2c, dc, w2c, p2c),
+                tw.c.ops.bias_finalize_batch([(pc, npc, C, b1c, nb, False), (p2c, npc, C, b2c, nb, True)])],
+               [tw.g.ops.in_bwd_bias_deferred(xg, sg, act, gg, bool(fold), g2g, dg, w2g, pg), tw.g.ops.in_bwd_bias_deferred(xg, sg, act, gg, bool(fold), g2g, dg, w2g, p2g),
+                tw.g.ops.bias_finalize_batch([(pg, npg, C, b1g, nb, False), (p2g, npg, C, b2g, nb, True)])])
+        atol_b = TOL[dtype][1] * 5 * (B * H * W) ** 0.5
+        np.testing.assert_allclose(b1g.cpu().numpy(), b1c.numpy(), rtol=TOL[dtype][0] * 5, atol=atol_b)
+        np.testing.assert_allclose(b2g.cpu().numpy() - 1.0, b1g.cpu().numpy(), rtol=1e-5, atol=1e-5 * (1 + float(b1g.abs().max())))   # accumulate = same sum + 1
+        tw.check(TOL[dtype][0] * 5, TOL[dtype][1] * 5)
         oc, og = tw.view(B, H, W, C, 0, rand=False)
         tw.run(tw.c.ops.fold_add(g2c, gc, bool(fold), oc), tw.g.ops.fold_add(g2g, gg, bool(fold), og))
         tw.run(tw.c.ops.act_bwd(yc, 3, gc, bool(fold), g2c, dc), tw.g.ops.act_bwd(yg, 3, gg, bool(fold), g2g, dg))
