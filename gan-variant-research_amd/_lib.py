@@ -28,7 +28,8 @@ class GanConvDesc(C.Structure):
                 ("in_", vp), ("in_Hp", i32), ("in_Wp", i32), ("in_y0", i32), ("in_x0", i32), ("in_sy", i32), ("in_sx", i32),
                 ("tapoff", vp), ("w", vp), ("bias", vp), ("out", vp),
                 ("out_Hp", i32), ("out_Wp", i32), ("out_C", i32), ("out_y0", i32), ("out_x0", i32), ("out_sy", i32), ("out_sx", i32),
-                ("act", i32), ("mask", vp), ("mask_Hp", i32), ("mask_Wp", i32), ("mask_y0", i32), ("mask_x0", i32), ("stats", vp), ("max_tapoff", i32), ("w_layout", i32)]
+                ("act", i32), ("mask", vp), ("mask_Hp", i32), ("mask_Wp", i32), ("mask_y0", i32), ("mask_x0", i32), ("stats", vp), ("max_tapoff", i32), ("w_layout", i32),
+                ("win_ty0", i32), ("win_tx0", i32)]
 
 
 class GanWgradDesc(C.Structure):
@@ -65,6 +66,7 @@ PROTOTYPES = {
     "gan_last_error": (C.c_char_p, []),
     "gan_version": (C.c_int, []),
     "gan_conv_igemm": (C.c_int, [PC, vp]),
+    "gan_conv_win7_ok": (C.c_int, [PC]),
     "gan_conv_wgrad": (C.c_int, [PW, vp]),
     "gan_wgrad_patch_splits": (C.c_int, [PW]),
     "gan_wgrad_reduce": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),

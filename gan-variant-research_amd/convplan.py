@@ -71,6 +71,10 @@ class _Pack:
             c.w, c.w_frag = self.wf, True
         else:
             c.w, c.w_frag = self.w, False
+            # the 64 -> 3 channel 7x7 layers: the window kernel reads the same row-major weight copy
+            rowmajor7 = len(self.taps) == 49 and all(t[:2] == (i // 7, i % 7) for i, t in enumerate(self.taps))
+            if rowmajor7 and self.ctx.ops.conv_win7_ok(c, 0, 0):
+                c.win7 = (0, 0)
         return c
 
     def tapoff(self, wp: int) -> torch.Tensor:

@@ -204,6 +204,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
 }  // namespace
 
 int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s);
+int gan_conv_win7_launch(const gan_conv_desc* d, hipStream_t s);
 
 extern "C" int gan_conv_igemm(const gan_conv_desc* d, void* stream) {
   GAN_CHECK(d, "conv: null descriptor");
@@ -228,6 +229,7 @@ extern "C" int gan_conv_igemm(const gan_conv_desc* d, void* stream) {
   GAN_CHECK(d->out_y0 >= 0 && d->out_x0 >= 0 && (d->Ho - 1) * d->out_sy + d->out_y0 < d->out_Hp && (d->Wo - 1) * d->out_sx + d->out_x0 < d->out_Wp,
             "conv: output window outside the allocation");
   if (d->w_layout == 1) return gan_conv_patch_launch(d, (hipStream_t)stream);
+  if (d->w_layout == 2) return gan_conv_win7_launch(d, (hipStream_t)stream);
   GAN_CHECK(d->w_layout == 0, "conv: bad w_layout %d", d->w_layout);
   ConvArgs a;
   a.in = (const char*)d->in; a.w = (const char*)d->w; a.bias = d->bias; a.out = (char*)d->out; a.mask = (const char*)d->mask;

@@ -1,0 +1,159 @@
+// 7x7, stride 1, 64 channels -> <= 8 channels: the generator's output convolution (generator_resnet_attn.py:157-162, 64 -> 3, tanh)
+// and the input gradient of its first convolution (:110-116, 64 -> 3), bf16 operands, fp32 accumulation.
+//
+// The generic kernel stages the activation tile once per TAP (49 times); here a block stages the 22x22-pixel window of its 16x16
+// output tile ONCE (62 KB, pixel pitch 144 B so that the 16 lanes of a ds_read_b128 group hit all 64 banks) and every tap is an LDS
+// offset.  N is only 3 (padded to the MFMA's 16), so the kernel is bound by LDS reads of the activation fragments, not by MFMA:
+// the 98 K-steps (49 taps x 2 half-channel groups) are dealt round-robin to the four waves, each wave keeps the weight fragments of
+// its <= 25 K-steps in registers (read once from the generic [Nw=16][49][64] packing), accumulates all 16 rows of the tile, and the
+// four partial tiles are summed through LDS before bias / tanh / store.  Two blocks fit a CU (2 x 70 KB LDS, <= 256 VGPRs).
+#include "common.h"
+
+namespace {
+
+constexpr int TS = 16, PW = TS + 6, PITCH = 144, PATCH_BYTES = PW * PW * PITCH;   // 69,696 B
+constexpr int NSTEP = 98, NJ = 25;
+
+struct Win7Args {
+  const char* in; const char* w; const float* bias; char* out;
+  int B, Ho, Wo, tiles_x, tiles_y;
+  int in_Hp, in_Wp, in_y0, in_x0, ty0, tx0;      // first tap of output (0,0) reads padded pixel (in_y0 + ty0, in_x0 + tx0)
+  int out_Hp, out_Wp, out_y0, out_x0;
+  int act;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_win7_kernel(Win7Args a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // consecutive logical tiles on one XCD (its L2 then serves the halo overlap between neighbouring windows)
+  const int G = gridDim.x;
+  const int q = G >> 3, r = G & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+  const int tile = xcd < r ? xcd * (q + 1) + k : r * (q + 1) + (xcd - r) * q + k;
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int b = tile / per_img, t2 = tile - b * per_img;
+  const int oy0 = (t2 / a.tiles_x) * TS, ox0 = (t2 % a.tiles_x) * TS;
+
+  // ---- weight fragments of this wave's K-steps (A operand: row n = lane&15, k = 8*(lane>>4)..+7)
+  u32x4_t bw[NJ];
+  {
+    const char* wl = a.w + (lane & 15) * (49 * 128) + (lane >> 4) * 16;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int s = wave + 4 * j;
+      const int t = min(s >> 1, 48), c = s & 1;
+      u32x4_t v = *reinterpret_cast<const u32x4_t*>(wl + t * 128 + c * 64);
+      if (s >= NSTEP) v = u32x4_t{0u, 0u, 0u, 0u};
+      bw[j] = v;
+    }
+  }
+  // ---- stage the window: 484 pixels x 8 chunks of 16 B; pixels outside the allocation read as zero (they only feed masked outputs).
+  //      All 16 loads of a lane are issued before the first LDS write: with two blocks (8 waves) per CU nothing else hides their latency.
+  {
+    const int ay0 = oy0 + a.in_y0 + a.ty0, ax0 = ox0 + a.in_x0 + a.tx0;
+    const char* img = a.in + (int64_t)b * a.in_Hp * a.in_Wp * 128;
+    constexpr int NIT = (PW * PW * 8 + 255) / 256;      // 16
+    u32x4_t st[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256;
+      const int p = i >> 3, ck = i & 7;
+      const int py = p / PW, px = p - py * PW;
+      const int ay = ay0 + py, ax = ax0 + px;
+      const bool ok = i < PW * PW * 8 && ay >= 0 && ay < a.in_Hp && ax >= 0 && ax < a.in_Wp;
+      const int64_t off = ok ? ((int64_t)ay * a.in_Wp + ax) * 128 + ck * 16 : 0;      // a safe address for the lanes that are masked
+      u32x4_t v = *reinterpret_cast<const u32x4_t*>(img + off);
+      if (!ok) v = u32x4_t{0u, 0u, 0u, 0u};
+      st[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256;
+      if (i < PW * PW * 8) *reinterpret_cast<u32x4_t*>(lds + (i >> 3) * PITCH + (i & 7) * 16) = st[it];
+    }
+  }
+  __syncthreads();
+
+  // ---- main loop: B operand = activations, column j = pixel x = lane&15 of row m, k = 8*(lane>>4)..+7
+  f32x4_t acc[TS];
+#pragma unroll
+  for (int m = 0; m < TS; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const char* la = lds + (lane & 15) * PITCH + (lane >> 4) * 16;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int s = wave + 4 * j;
+    const int t = min(s >> 1, 48), c = s & 1;
+    const int ky = t / 7, kx = t - ky * 7;
+    const char* lj = la + (ky * PW + kx) * PITCH + c * 64;
+#pragma unroll
+    for (int m = 0; m < TS; ++m) {
+      const u32x4_t xa = *reinterpret_cast<const u32x4_t*>(lj + m * (PW * PITCH));
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bw[j]), __builtin_bit_cast(bf16x8_t, xa), acc[m], 0, 0, 0);
+    }
+  }
+  __syncthreads();                       // every wave is done with the window: its space becomes the reduction buffer
+  // acc[m]: row n = 4*(lane>>4)+r, column x = lane&15  ->  red[wave][m][x][n]
+  {
+    float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int m = 0; m < TS; ++m)
+      *reinterpret_cast<f32x4_t*>(red + (((wave * TS + m) * TS + (lane & 15)) * 16 + (lane >> 4) * 4)) = acc[m];
+  }
+  __syncthreads();
+  // ---- one output pixel per thread: sum the four partial tiles, bias, activation, 8 bf16 channels = 16 bytes
+  {
+    const float* red = reinterpret_cast<const float*>(lds);
+    const int m = tid >> 4, x = tid & 15;
+    float v[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) v[n] = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {
+      const f32x4_t p0 = *reinterpret_cast<const f32x4_t*>(red + (((w2 * TS + m) * TS + x) * 16));
+      const f32x4_t p1 = *reinterpret_cast<const f32x4_t*>(red + (((w2 * TS + m) * TS + x) * 16 + 4));
+      v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+    }
+    const int oy = oy0 + m, ox = ox0 + x;
+    if (oy < a.Ho && ox < a.Wo) {
+#pragma unroll
+      for (int n = 0; n < 8; ++n) v[n] = act_apply(v[n], a.act);
+      bf16_t* o = reinterpret_cast<bf16_t*>(a.out) + (((int64_t)b * a.out_Hp + oy + a.out_y0) * a.out_Wp + ox + a.out_x0) * 8;
+      Chunk<bf16_t>::store(o, v);
+    }
+  }
+}
+}  // namespace
+
+// Host predicate: the descriptor is a 7x7 window convolution this kernel covers.  win_ty0 / win_tx0 give the first tap's position
+// (tapoff[t] must be ((win_ty0 + t/7) * in_Wp + win_tx0 + t%7) * Cin, which max_tapoff lets the library cross-check).
+extern "C" int gan_conv_win7_ok(const gan_conv_desc* d) {
+  if (!d || d->dtype != GAN_BF16 || d->Cin != 64 || d->ntaps != 49 || d->Nw != 16 || d->Nst != 8 || d->out_C != 8) return 0;
+  if (d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->mask || d->stats) return 0;
+  if (d->act != GAN_ACT_NONE && d->act != GAN_ACT_TANH) return 0;
+  if (d->max_tapoff != ((d->win_ty0 + 6) * d->in_Wp + d->win_tx0 + 6) * d->Cin) return 0;
+  { const char* e = getenv("GAN_NO_WIN7"); if (e && atoi(e)) return 0; }
+  return 1;
+}
+
+int gan_conv_win7_launch(const gan_conv_desc* d, hipStream_t s) {
+  GAN_CHECK(gan_conv_win7_ok(d), "conv: w_layout 2 set on a descriptor the 7x7 window kernel does not cover");
+  // every tap of every real output pixel must lie inside the allocation (the planner's halos guarantee it; checked here)
+  GAN_CHECK(d->in_y0 + d->win_ty0 >= 0 && d->in_x0 + d->win_tx0 >= 0 && d->Ho - 1 + d->in_y0 + d->win_ty0 + 6 < d->in_Hp &&
+                d->Wo - 1 + d->in_x0 + d->win_tx0 + 6 < d->in_Wp, "conv(7x7 window): taps reach outside the input allocation");
+  Win7Args a;
+  a.in = (const char*)d->in; a.w = (const char*)d->w; a.bias = d->bias; a.out = (char*)d->out;
+  a.B = d->B; a.Ho = d->Ho; a.Wo = d->Wo; a.tiles_x = (d->Wo + TS - 1) / TS; a.tiles_y = (d->Ho + TS - 1) / TS;
+  a.in_Hp = d->in_Hp; a.in_Wp = d->in_Wp; a.in_y0 = d->in_y0; a.in_x0 = d->in_x0; a.ty0 = d->win_ty0; a.tx0 = d->win_tx0;
+  a.out_Hp = d->out_Hp; a.out_Wp = d->out_Wp; a.out_y0 = d->out_y0; a.out_x0 = d->out_x0;
+  a.act = d->act;
+  const int64_t blocks = (int64_t)d->B * a.tiles_x * a.tiles_y;
+  GAN_CHECK(blocks < (1ll << 31), "conv(7x7 window): too many tiles");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv_win7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PATCH_BYTES + 64) != hipSuccess)
+      return gan_set_error(-2, "conv(7x7 window): cannot raise the dynamic LDS limit to %d bytes", PATCH_BYTES + 64);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_win7_kernel, dim3((unsigned)blocks), dim3(256), PATCH_BYTES + 64, s, a);
+  GAN_LAUNCH_CHECK();
+  return 0;
+}

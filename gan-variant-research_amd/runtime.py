@@ -95,6 +95,7 @@ class ConvCall:
     max_tapoff: int = 0
     w_frag: bool = False      # w is the fragment-major copy (range-patch kernel)
     stats: Optional[torch.Tensor] = None   # InstanceNorm partials written by the epilogue (see HipOps.conv_stats_parts)
+    win7: Optional[tuple] = None           # (ty0, tx0): run by the 7x7 window kernel, taps row-major from that position (w_layout 2)
 
 
 @dataclass
@@ -246,12 +247,21 @@ class HipOps:
         d.stats = c.stats.data_ptr() if c.stats is not None else None
         d.max_tapoff = c.max_tapoff
         d.w_layout = 1 if c.w_frag else 0
+        if c.win7 is not None:
+            assert not c.w_frag
+            d.w_layout, d.win_ty0, d.win_tx0 = 2, c.win7[0], c.win7[1]
         assert c.out.dtype == c.x.dtype
         return d
 
     def conv_patch_ok(self, c: ConvCall) -> bool:
         """True if the range-patch kernel takes this call (then `c.w` must be the fragment-major weight copy)."""
         return bool(self.lib.gan_conv_patch_ok(C.byref(self._conv_desc(c))))
+
+    def conv_win7_ok(self, c: ConvCall, ty0: int, tx0: int) -> bool:
+        """True if the 7x7 window kernel takes this call with its 49 row-major taps starting at (ty0, tx0)."""
+        d = self._conv_desc(c)
+        d.win_ty0, d.win_tx0 = ty0, tx0
+        return bool(self.lib.gan_conv_win7_ok(C.byref(d)))
 
     def conv_stats_parts(self, c: ConvCall) -> int:
         """Pixel tiles per image for which this call can write InstanceNorm partials in its epilogue (0: it cannot)."""

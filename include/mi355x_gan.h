@@ -62,7 +62,9 @@ typedef struct gan_conv_desc {
                                     rounding to the output type), written with plain stores (deterministic); act must be none */
   int32_t max_tapoff;            /* largest value in tapoff[] (needed by the range-patch kernel's span check) */
   int32_t w_layout;              /* 0: w is [Nw][ntaps][Cin] (generic kernel); 1: fragment-major [Nw/16][ntaps*Cin/32][64][8]
-                                    for the range-patch kernel (the descriptor must satisfy gan_conv_patch_ok) */
+                                    for the range-patch kernel (the descriptor must satisfy gan_conv_patch_ok); 2: w as for 0, run
+                                    by the 7x7 window kernel (the descriptor must satisfy gan_conv_win7_ok) */
+  int32_t win_ty0, win_tx0;      /* w_layout 2: tapoff[t] = ((win_ty0 + t/7) * in_Wp + win_tx0 + t%7) * Cin, t = 0..48 */
 } gan_conv_desc;
 
 /* Weight-gradient GEMM: part[s][n][t][c] = sum over the rows m of split s of
@@ -94,6 +96,9 @@ int gan_conv_igemm(const gan_conv_desc* d, void* stream);
 /* 1 if the descriptor qualifies for the range-patch kernel (bf16, Cin % 64 == 0, Nw % 128 == 0, one tile's pixel span fits
  * the LDS slab); pure host-side predicate used by the planner to choose the weight layout */
 int gan_conv_patch_ok(const gan_conv_desc* d);
+/* 1 if the descriptor qualifies for the 7x7 window kernel (bf16, stride 1, 49 row-major taps located by win_ty0/win_tx0,
+ * Cin = 64, Nw = 16, Nst = out_C = 8, act none or tanh, no mask / stats): the 64 -> 3 channel 7x7 layers */
+int gan_conv_win7_ok(const gan_conv_desc* d);
 /* pixel tiles per image for which the descriptor's launch writes InstanceNorm partials to d->stats; 0: it cannot (then use gan_in_stats) */
 int gan_conv_stats_parts(const gan_conv_desc* d);
 int gan_conv_wgrad(const gan_wgrad_desc* d, void* stream);

@@ -41,6 +41,9 @@ GEOMS = [  # cin, cout, k, s, p, transposed, H, reflect
     (256, 512, 4, 1, 1, False, 9, False),
     (512, 1, 4, 1, 1, False, 8, False),
     (128, 256, 4, 2, 1, False, 16, False),
+    # the 64 <-> 3 channel 7x7 layers on multi-tile images with ragged edges (7x7 window kernel: forward of 64->3, input gradient of 3->64)
+    (64, 3, 7, 1, 3, False, 37, True),
+    (3, 64, 7, 1, 3, False, 21, True),
 ]
 
 

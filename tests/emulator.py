@@ -107,6 +107,12 @@ class EmuOps:
         rows_used = min(-(-m_img // 256) * 256, -(-m_img // 288) * 288)       # tile utilisation >= 75 % once the CUs are full
         return 4 * m_img >= 3 * rows_used
 
+    def conv_win7_ok(self, c, ty0, tx0):
+        """Mirror of gan_conv_win7_ok (the emulator computes every call the same way; the flag only has to agree with the library)."""
+        return (c.x.dtype == 1 and c.Cin == 64 and c.ntaps == 49 and c.Nw == 16 and c.Nst == 8 and c.out.C == 8 and c.in_sy == 1 and c.in_sx == 1
+                and c.out_sy == 1 and c.out_sx == 1 and c.mask is None and c.stats is None and c.act in (ACT_NONE, ACT_TANH)
+                and c.max_tapoff == ((ty0 + 6) * c.x.Wp + tx0 + 6) * c.Cin)
+
     def conv_stats_parts(self, c):
         """Statement of gan_conv_stats_parts; the emulator reports one part per image."""
         return 1 if (self.conv_patch_ok(c) and c.act == ACT_NONE and c.mask is None and (c.out_sy, c.out_sx) == (1, 1)) else 0

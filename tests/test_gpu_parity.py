@@ -29,6 +29,18 @@ def test_conv_geometry_hip_tile288(geom, monkeypatch):
     cases.run_conv_geometry(hip_ctx(BF16), geom, BF16, B=3)
 
 
+@pytest.mark.parametrize("geom", [g for g in cases.GEOMS if g[2] == 7 and max(g[0], g[1]) == 64])
+def test_conv_7x7_window_kernel_is_taken(geom):
+    """The 64 <-> 3 channel 7x7 layers run on the window kernel in bf16 (forward of 64->3; input gradient of 3->64) and stay correct
+    (run_conv_geometry compares with torch); GAN_NO_WIN7=1 would send them back to the generic kernel."""
+    ctx = hip_ctx(BF16)
+    seen = []
+    orig = ctx.ops.conv_igemm
+    ctx.ops.conv_igemm = lambda c: (seen.append(c.win7), orig(c))[1]
+    cases.run_conv_geometry(ctx, geom, BF16, B=3)
+    assert any(w is not None for w in seen), "no call was planned onto the 7x7 window kernel"
+
+
 # ---------------------------------------------------------------------------------------------- op twins
 class Twin:
     """The same buffers on CPU (emulator) and GPU (HIP); ops are built on both and every buffer is compared afterwards."""
