@@ -121,14 +121,89 @@ __global__ __launch_bounds__(256, 2) void conv_win7_kernel(Win7Args a) {
     }
   }
 }
+// ---- the mirror case, 3 (padded 8) -> 64 channels: the generator's first convolution (generator_resnet_attn.py:110-116) and the input
+// gradient of its output convolution.  A pixel is one 16-byte chunk, so a K-step of 32 is FOUR taps (lane group g = lane>>4 reads tap
+// 4*ks+g); 49 taps = 13 K-steps against the generic kernel's 56 tap slots, and the 22x22 window is 7.7 KB.  Wave w owns output channels
+// 16w..16w+15 for all 16 rows of the tile (13 weight fragments in registers); results go straight to HBM, 8 bytes per lane.
+constexpr int KS3 = 13;
+
+__global__ __launch_bounds__(256, 2) void conv_win7_from3_kernel(Win7Args a, int wtaps) {
+  __shared__ __attribute__((aligned(16))) char lds[(PW * PW + 16) * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = gridDim.x;
+  const int q = G >> 3, r = G & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+  const int tile = xcd < r ? xcd * (q + 1) + k : r * (q + 1) + (xcd - r) * q + k;
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int b = tile / per_img, t2 = tile - b * per_img;
+  const int oy0 = (t2 / a.tiles_x) * TS, ox0 = (t2 % a.tiles_x) * TS;
+  // weights: row n = 16*wave + (lane&15) of [64][wtaps][8]; K-step ks, lane group g -> tap 4*ks+g (taps >= 49 are zero in the packing)
+  u32x4_t bw[KS3];
+  {
+    const char* wl = a.w + ((int64_t)(wave * 16 + (lane & 15)) * wtaps + (lane >> 4)) * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS3; ++ks) bw[ks] = *reinterpret_cast<const u32x4_t*>(wl + ks * 64);
+  }
+  {
+    const int ay0 = oy0 + a.in_y0 + a.ty0, ax0 = ox0 + a.in_x0 + a.tx0;
+    const char* img = a.in + (int64_t)b * a.in_Hp * a.in_Wp * 16;
+    u32x4_t st[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int p = tid + it * 256;
+      const int py = p / PW, px = p - py * PW;
+      const int ay = ay0 + py, ax = ax0 + px;
+      const bool ok = p < PW * PW && ay >= 0 && ay < a.in_Hp && ax >= 0 && ax < a.in_Wp;
+      u32x4_t v = *reinterpret_cast<const u32x4_t*>(img + (ok ? ((int64_t)ay * a.in_Wp + ax) * 16 : 0));
+      if (!ok) v = u32x4_t{0u, 0u, 0u, 0u};
+      st[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+      if (tid + it * 256 < PW * PW + 16) *reinterpret_cast<u32x4_t*>(lds + (tid + it * 256) * 16) = st[it];   // +16: slack read by the padding taps
+  }
+  __syncthreads();
+  f32x4_t acc[TS];
+#pragma unroll
+  for (int m = 0; m < TS; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int g = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < KS3; ++ks) {
+    const int t = min(4 * ks + g, 48);                      // taps 49..51: zero weights, any in-window address will do
+    const int ky = t / 7, kx = t - ky * 7;
+    const char* lj = lds + ((ky * PW + kx) + (lane & 15)) * 16;
+#pragma unroll
+    for (int m = 0; m < TS; ++m) {
+      const u32x4_t xa = *reinterpret_cast<const u32x4_t*>(lj + m * (PW * 16));
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bw[ks]), __builtin_bit_cast(bf16x8_t, xa), acc[m], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);      // keep one K-step's 16 fragment reads in flight, not all 13 K-steps' (register pressure)
+  }
+  // acc[m]: channel n = 16*wave + 4*g + r, pixel x = lane&15 of row m
+  const int n0 = wave * 16 + g * 4, x = lane & 15;
+  float bias[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bias[i] = a.bias ? a.bias[n0 + i] : 0.f;
+  bf16_t* dst = reinterpret_cast<bf16_t*>(a.out) + (((int64_t)b * a.out_Hp + oy0 + a.out_y0) * a.out_Wp + ox0 + x + a.out_x0) * 64 + n0;
+  const bool xok = ox0 + x < a.Wo;
+#pragma unroll
+  for (int m = 0; m < TS; ++m) {
+    uint2 o;                                                 // no activation on this path (gan_conv_win7_ok)
+    o.x = (uint32_t)f2bf(acc[m].x + bias[0]) | ((uint32_t)f2bf(acc[m].y + bias[1]) << 16);
+    o.y = (uint32_t)f2bf(acc[m].z + bias[2]) | ((uint32_t)f2bf(acc[m].w + bias[3]) << 16);
+    if (xok && oy0 + m < a.Ho) *reinterpret_cast<uint2*>(dst + (int64_t)m * a.out_Wp * 64) = o;
+  }
+}
 }  // namespace
 
 // Host predicate: the descriptor is a 7x7 window convolution this kernel covers.  win_ty0 / win_tx0 give the first tap's position
 // (tapoff[t] must be ((win_ty0 + t/7) * in_Wp + win_tx0 + t%7) * Cin, which max_tapoff lets the library cross-check).
 extern "C" int gan_conv_win7_ok(const gan_conv_desc* d) {
-  if (!d || d->dtype != GAN_BF16 || d->Cin != 64 || d->ntaps != 49 || d->Nw != 16 || d->Nst != 8 || d->out_C != 8) return 0;
+  if (!d || d->dtype != GAN_BF16) return 0;
+  const bool to3 = d->Cin == 64 && d->ntaps == 49 && d->Nw == 16 && d->Nst == 8 && d->out_C == 8;
+  const bool from3 = d->Cin == 8 && d->ntaps >= 52 && d->Nw == 64 && d->Nst == 64 && d->out_C == 64;
+  if (!to3 && !from3) return 0;
   if (d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->mask || d->stats) return 0;
-  if (d->act != GAN_ACT_NONE && d->act != GAN_ACT_TANH) return 0;
+  if (d->act != GAN_ACT_NONE && !(to3 && d->act == GAN_ACT_TANH)) return 0;
   if (d->max_tapoff != ((d->win_ty0 + 6) * d->in_Wp + d->win_tx0 + 6) * d->Cin) return 0;
   { const char* e = getenv("GAN_NO_WIN7"); if (e && atoi(e)) return 0; }
   return 1;
@@ -152,6 +227,11 @@ int gan_conv_win7_launch(const gan_conv_desc* d, hipStream_t s) {
     if (hipFuncSetAttribute((const void*)conv_win7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PATCH_BYTES + 64) != hipSuccess)
       return gan_set_error(-2, "conv(7x7 window): cannot raise the dynamic LDS limit to %d bytes", PATCH_BYTES + 64);
     attr_set = true;
+  }
+  if (d->Cin == 8) {
+    hipLaunchKernelGGL(conv_win7_from3_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, d->ntaps);
+    GAN_LAUNCH_CHECK();
+    return 0;
   }
   hipLaunchKernelGGL(conv_win7_kernel, dim3((unsigned)blocks), dim3(256), PATCH_BYTES + 64, s, a);
   GAN_LAUNCH_CHECK();

@@ -96,8 +96,9 @@ int gan_conv_igemm(const gan_conv_desc* d, void* stream);
 /* 1 if the descriptor qualifies for the range-patch kernel (bf16, Cin % 64 == 0, Nw % 128 == 0, one tile's pixel span fits
  * the LDS slab); pure host-side predicate used by the planner to choose the weight layout */
 int gan_conv_patch_ok(const gan_conv_desc* d);
-/* 1 if the descriptor qualifies for the 7x7 window kernel (bf16, stride 1, 49 row-major taps located by win_ty0/win_tx0,
- * Cin = 64, Nw = 16, Nst = out_C = 8, act none or tanh, no mask / stats): the 64 -> 3 channel 7x7 layers */
+/* 1 if the descriptor qualifies for a 7x7 window kernel (bf16, stride 1, 49 row-major taps located by win_ty0/win_tx0, act none or
+ * tanh, no mask / stats): Cin = 64, Nw = 16, Nst = out_C = 8 (the 64 -> 3 channel layers) or Cin = 8, Nw = Nst = out_C = 64 with the
+ * tap list padded to >= 52 (the 3 -> 64 channel layers) */
 int gan_conv_win7_ok(const gan_conv_desc* d);
 /* pixel tiles per image for which the descriptor's launch writes InstanceNorm partials to d->stats; 0: it cannot (then use gan_in_stats) */
 int gan_conv_stats_parts(const gan_conv_desc* d);

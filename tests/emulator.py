@@ -109,8 +109,10 @@ class EmuOps:
 
     def conv_win7_ok(self, c, ty0, tx0):
         """Mirror of gan_conv_win7_ok (the emulator computes every call the same way; the flag only has to agree with the library)."""
-        return (c.x.dtype == 1 and c.Cin == 64 and c.ntaps == 49 and c.Nw == 16 and c.Nst == 8 and c.out.C == 8 and c.in_sy == 1 and c.in_sx == 1
-                and c.out_sy == 1 and c.out_sx == 1 and c.mask is None and c.stats is None and c.act in (ACT_NONE, ACT_TANH)
+        to3 = c.Cin == 64 and c.ntaps == 49 and c.Nw == 16 and c.Nst == 8 and c.out.C == 8
+        from3 = c.Cin == 8 and c.ntaps >= 52 and c.Nw == 64 and c.Nst == 64 and c.out.C == 64
+        return (c.x.dtype == 1 and (to3 or from3) and c.in_sy == 1 and c.in_sx == 1
+                and c.out_sy == 1 and c.out_sx == 1 and c.mask is None and c.stats is None and (c.act == ACT_NONE or (to3 and c.act == ACT_TANH))
                 and c.max_tapoff == ((ty0 + 6) * c.x.Wp + tx0 + 6) * c.Cin)
 
     def conv_stats_parts(self, c):

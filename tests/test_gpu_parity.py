@@ -31,14 +31,15 @@ def test_conv_geometry_hip_tile288(geom, monkeypatch):
 
 @pytest.mark.parametrize("geom", [g for g in cases.GEOMS if g[2] == 7 and max(g[0], g[1]) == 64])
 def test_conv_7x7_window_kernel_is_taken(geom):
-    """The 64 <-> 3 channel 7x7 layers run on the window kernel in bf16 (forward of 64->3; input gradient of 3->64) and stay correct
-    (run_conv_geometry compares with torch); GAN_NO_WIN7=1 would send them back to the generic kernel."""
+    """The 64 <-> 3 channel 7x7 layers run on the two window kernels in bf16 (64->3: output conv forward, first conv's input gradient;
+    3->64: first conv forward, output conv's input gradient) and stay correct (run_conv_geometry compares with torch);
+    GAN_NO_WIN7=1 would send them back to the generic kernel."""
     ctx = hip_ctx(BF16)
     seen = []
     orig = ctx.ops.conv_igemm
     ctx.ops.conv_igemm = lambda c: (seen.append(c.win7), orig(c))[1]
     cases.run_conv_geometry(ctx, geom, BF16, B=3)
-    assert any(w is not None for w in seen), "no call was planned onto the 7x7 window kernel"
+    assert sum(w is not None for w in seen) == 2, f"forward and input gradient should both run on the 7x7 window kernels: {seen}"
 
 
 # ---------------------------------------------------------------------------------------------- op twins
