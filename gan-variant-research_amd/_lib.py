@@ -69,6 +69,7 @@ PROTOTYPES = {
     "gan_conv_win7_ok": (C.c_int, [PC]),
     "gan_conv_wgrad": (C.c_int, [PW, vp]),
     "gan_wgrad_patch_splits": (C.c_int, [PW]),
+    "gan_wgrad_win7_splits": (C.c_int, [PW]),
     "gan_wgrad_reduce": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "gan_conv_patch_ok": (C.c_int, [PC]),
     "gan_conv_stats_parts": (C.c_int, [PC]),

@@ -253,8 +253,11 @@ class ConvLayer:
         call = WgradCall(g.B, g.H, g.W, cx, self.kk, n, 1, xo, xo.halo - p, xo.halo - p, stride, stride, tapoff, g, g.halo, g.halo, 1, 1, None,
                          max_tapoff=((k - 1) * xo.Wp + (k - 1)) * cx)
         spi = ops.wgrad_patch_splits(call)
+        w7 = ops.wgrad_win7_splits(call) if spi == 0 else 0
         if spi > 0:      # range-patch kernel: splits never cross an image
             call.nsplit, call.variant = g.B * spi, 1
+        elif w7 > 0:     # the 64 -> 3 channel 7x7 layer: one slab per persistent block
+            call.nsplit, call.variant = w7, 2
         else:
             call.nsplit = self._nsplit(m, -(-ktot // jt), -(-n // ntl), n <= 16)
         ns = call.nsplit

@@ -334,10 +334,12 @@ __global__ __launch_bounds__(256) void bias_grad_stage2(const float* __restrict_
 }  // namespace
 
 int gan_wgrad_patch_launch(const gan_wgrad_desc* d, hipStream_t s);
+int gan_wgrad_win7_launch(const gan_wgrad_desc* d, hipStream_t s);
 
 extern "C" int gan_conv_wgrad(const gan_wgrad_desc* d, void* stream) {
   GAN_CHECK(d, "wgrad: null descriptor");
   if (d->variant == 1) return gan_wgrad_patch_launch(d, (hipStream_t)stream);
+  if (d->variant == 2) return gan_wgrad_win7_launch(d, (hipStream_t)stream);
   GAN_CHECK(d->dtype == GAN_F32 || d->dtype == GAN_BF16, "wgrad: bad dtype");
   const int es = d->dtype == GAN_F32 ? 4 : 2, epc = 16 / es;
   GAN_CHECK(d->Cx >= 8 && (d->Cx & (d->Cx - 1)) == 0, "wgrad: Cx=%d must be a power of two >= 8", d->Cx);

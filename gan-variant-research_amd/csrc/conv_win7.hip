@@ -3,16 +3,16 @@
 //
 // The generic kernel stages the activation tile once per TAP (49 times); here a block stages the 22x22-pixel window of its 16x16
 // output tile ONCE (62 KB, pixel pitch 144 B so that the 16 lanes of a ds_read_b128 group hit all 64 banks) and every tap is an LDS
-// offset.  N is only 3 (padded to the MFMA's 16), so the kernel is bound by LDS reads of the activation fragments, not by MFMA:
-// the 98 K-steps (49 taps x 2 half-channel groups) are dealt round-robin to the four waves, each wave keeps the weight fragments of
-// its <= 25 K-steps in registers (read once from the generic [Nw=16][49][64] packing), accumulates all 16 rows of the tile, and the
-// four partial tiles are summed through LDS before bias / tanh / store.  Two blocks fit a CU (2 x 70 KB LDS, <= 256 VGPRs).
+// offset.  N is only 3 (padded to the MFMA's 16).  The 14 (column shift, half-channel group) pairs are dealt to the four waves; a wave
+// keeps the weight fragments of its pairs for all 7 tap rows in registers (read once from the generic [Nw=16][49][64] packing), reads
+// each activation fragment once and uses it for every tap row, accumulates all 16 rows of the tile, and the four partial tiles are
+// summed through LDS before bias / tanh / store.  Two blocks fit a CU (2 x 70 KB LDS, <= 256 VGPRs).
 #include "common.h"
 
 namespace {
 
 constexpr int TS = 16, PW = TS + 6, PITCH = 144, PATCH_BYTES = PW * PW * PITCH;   // 69,696 B
-constexpr int NSTEP = 98, NJ = 25;
+constexpr int NJ = 4;
 
 struct Win7Args {
   const char* in; const char* w; const float* bias; char* out;
@@ -33,17 +33,20 @@ __global__ __launch_bounds__(256, 2) void conv_win7_kernel(Win7Args a) {
   const int b = tile / per_img, t2 = tile - b * per_img;
   const int oy0 = (t2 / a.tiles_x) * TS, ox0 = (t2 % a.tiles_x) * TS;
 
-  // ---- weight fragments of this wave's K-steps (A operand: row n = lane&15, k = 8*(lane>>4)..+7)
-  u32x4_t bw[NJ];
+  // ---- work split: the 14 (column shift kx, half-channel group c) pairs are dealt to the waves (4,4,3,3); a wave holds the weight
+  //      fragments of its pairs for all 7 tap rows (A operand: row n = lane&15, k = 8*(lane>>4)..+7)
+  u32x4_t bw[NJ][7];
   {
     const char* wl = a.w + (lane & 15) * (49 * 128) + (lane >> 4) * 16;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int s = wave + 4 * j;
-      const int t = min(s >> 1, 48), c = s & 1;
-      u32x4_t v = *reinterpret_cast<const u32x4_t*>(wl + t * 128 + c * 64);
-      if (s >= NSTEP) v = u32x4_t{0u, 0u, 0u, 0u};
-      bw[j] = v;
+      const int id = wave + 4 * j, kx = min(id >> 1, 6), c = id & 1;
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        u32x4_t v = *reinterpret_cast<const u32x4_t*>(wl + (ky * 7 + kx) * 128 + c * 64);
+        if (id >= 14) v = u32x4_t{0u, 0u, 0u, 0u};
+        bw[j][ky] = v;
+      }
     }
   }
   // ---- stage the window: 484 pixels x 8 chunks of 16 B; pixels outside the allocation read as zero (they only feed masked outputs).
@@ -77,18 +80,24 @@ __global__ __launch_bounds__(256, 2) void conv_win7_kernel(Win7Args a) {
   f32x4_t acc[TS];
 #pragma unroll
   for (int m = 0; m < TS; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // an activation fragment -- window row R, shift kx, group c -- is read once and feeds every tap row ky with output row m = R - ky:
+  // 22 reads and up to 7 x 16 MFMAs per pair instead of one read per MFMA (the loop was LDS-bound)
   const char* la = lds + (lane & 15) * PITCH + (lane >> 4) * 16;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int s = wave + 4 * j;
-    const int t = min(s >> 1, 48), c = s & 1;
-    const int ky = t / 7, kx = t - ky * 7;
-    const char* lj = la + (ky * PW + kx) * PITCH + c * 64;
+    const int id = wave + 4 * j, kx = min(id >> 1, 6), c = id & 1;
+    const char* lj = la + kx * PITCH + c * 64;
 #pragma unroll
-    for (int m = 0; m < TS; ++m) {
-      const u32x4_t xa = *reinterpret_cast<const u32x4_t*>(lj + m * (PW * PITCH));
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bw[j]), __builtin_bit_cast(bf16x8_t, xa), acc[m], 0, 0, 0);
+    for (int R = 0; R < PW; ++R) {
+      const u32x4_t xa = *reinterpret_cast<const u32x4_t*>(lj + R * (PW * PITCH));
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        const int m = R - ky;
+        if (m >= 0 && m < TS)
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bw[j][ky]), __builtin_bit_cast(bf16x8_t, xa), acc[m], 0, 0, 0);
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();                       // every wave is done with the window: its space becomes the reduction buffer
   // acc[m]: row n = 4*(lane>>4)+r, column x = lane&15  ->  red[wave][m][x][n]
@@ -234,6 +243,155 @@ int gan_conv_win7_launch(const gan_conv_desc* d, hipStream_t s) {
     return 0;
   }
   hipLaunchKernelGGL(conv_win7_kernel, dim3((unsigned)blocks), dim3(256), PATCH_BYTES + 64, s, a);
+  GAN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient, 64 -> 3 channel layer
+// dW[co][ky][kx][ci] = sum over pixels of dY[pixel][co] * X[pixel + (ky,kx)][ci] for the generator's output convolution
+// (generator_resnet_attn.py:157-162): 49 taps x 64 channels x 3 (padded 8) outputs, reduced over B*H*W pixels.  The generic kernel
+// re-stages the X tile per tap; here a block walks 16x16 pixel tiles, stages each tile's 22x22 window once (the forward kernel's layout)
+// and keeps the WHOLE gradient in registers: wave w owns input channels 16w..16w+15 for all 49 taps = 49 accumulator tiles.
+// Pixels are the K dimension, so both operands are read through ds_read_b64_tr_b16 (channel-major fragments from pixel-major LDS).
+// Every block writes one partial [8][49][64] slab; gan_wgrad_reduce sums the slabs (deterministic, no atomics).
+namespace {
+
+struct Wg7Args {
+  const char* x; const char* g; float* part;
+  int B, Ho, Wo, tiles_x, tiles_y, ntiles;
+  int x_Hp, x_Wp, x_y0, x_x0;       // tap (0,0) of pixel (0,0) reads padded x pixel (x_y0, x_x0)
+  int g_Hp, g_Wp, g_y0, g_x0;
+};
+
+constexpr int GP = 32;                                   // bytes per pixel of the dY tile in LDS: 8 real + 8 zero channel slots
+// window pitch 160 B here: a transposing read's 32 lanes touch 8 consecutive pixels x 32 B, and 40 banks per pixel spreads their
+// starts over 0,40,16,56,32,8,48,24 -- every bank once (the forward kernel's 16-lane b128 groups want 144 instead)
+constexpr int WPITCH = 160, WPATCH = PW * PW * WPITCH;
+constexpr int WG7_LDS = WPATCH + 64 + TS * TS * GP;
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__global__ __launch_bounds__(256, 1) void wgrad_win7_kernel(Wg7Args a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* lx = lds;
+  char* lg = lds + WPATCH + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fi = lane & 15, fg = lane >> 4, q = fi >> 2, p = fi & 3;
+  f32x4_t acc[49];
+#pragma unroll
+  for (int t = 0; t < 49; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int per_img = a.tiles_x * a.tiles_y;
+  // lane (q, p) of a 16-lane group addresses pixel q of a 4-pixel block, channels 4p..4p+3.  The K index 8*fg + 4*h + q of a K-step
+  // (32 pixels = a row pair) is mapped to the pixel (row fg>>1, x = 8*h + 4*(fg&1) + q) -- any bijection does, as long as both operands
+  // use it -- so that one read instruction's lane groups fg = 0,1 cover 8 CONSECUTIVE pixels (bank-conflict free at pitch 160)
+  int xoff[2], goff[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = fg >> 1, xx = h * 8 + (fg & 1) * 4 + q;
+    xoff[h] = (r * PW + xx) * WPITCH + (wave * 16 + p * 4) * 2;
+    goff[h] = (r * TS + xx) * GP + p * 8;
+  }
+  // The next tile's window and dY chunk are fetched into registers while the current tile is multiplied (one block per CU: nothing
+  // else would hide the global latency), and written to LDS when the current tile's reads are done.
+  constexpr int NIT = (PW * PW * 8 + 255) / 256;
+  u32x4_t st[NIT], gv;
+  auto fetch = [&](int tile) {
+    const int b = tile / per_img, t2 = tile - b * per_img;
+    const int oy0 = (t2 / a.tiles_x) * TS, ox0 = (t2 % a.tiles_x) * TS;
+    const int ay0 = oy0 + a.x_y0, ax0 = ox0 + a.x_x0;
+    const char* img = a.x + (int64_t)b * a.x_Hp * a.x_Wp * 128;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256;
+      const int px_ = i >> 3, ck = i & 7;
+      const int py = px_ / PW, px = px_ - py * PW;
+      const int ay = ay0 + py, ax = ax0 + px;
+      const bool ok = i < PW * PW * 8 && ay >= 0 && ay < a.x_Hp && ax >= 0 && ax < a.x_Wp;
+      u32x4_t v = *reinterpret_cast<const u32x4_t*>(img + (ok ? ((int64_t)ay * a.x_Wp + ax) * 128 + ck * 16 : 0));
+      if (!ok) v = u32x4_t{0u, 0u, 0u, 0u};
+      st[it] = v;
+    }
+    // dY tile: pixels outside the image contribute nothing (zero)
+    const int gy = oy0 + (tid >> 4), gx = ox0 + (tid & 15);
+    gv = u32x4_t{0u, 0u, 0u, 0u};
+    if (gy < a.Ho && gx < a.Wo) gv = *reinterpret_cast<const u32x4_t*>(a.g + (((int64_t)b * a.g_Hp + gy + a.g_y0) * a.g_Wp + gx + a.g_x0) * 16);
+  };
+  if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    __syncthreads();                                   // the previous tile's LDS reads are done
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256;
+      if (i < PW * PW * 8) *reinterpret_cast<u32x4_t*>(lx + (i >> 3) * WPITCH + (i & 7) * 16) = st[it];
+    }
+    *reinterpret_cast<u32x4_t*>(lg + tid * GP) = gv;
+    *reinterpret_cast<u32x4_t*>(lg + tid * GP + 16) = u32x4_t{0u, 0u, 0u, 0u};
+    __syncthreads();
+    if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
+    // dY fragments of the 8 K-steps (row pairs 2ks, 2ks+1) stay in registers; an X fragment -- window row pair R, column shift kx -- is
+    // read ONCE and feeds every (tap row ky, K-step ks) with 2ks + ky == R: 147 fragment reads per tile instead of 392
+    bf16x8_t gfr[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const s16x4_t g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lg + ks * (2 * TS * GP) + goff[0]));
+      const s16x4_t g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lg + ks * (2 * TS * GP) + goff[1]));
+      gfr[ks] = bf16x8_t{g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+    }
+#pragma unroll
+    for (int R = 0; R <= 20; ++R) {
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        const int tb = (R * PW + kx) * WPITCH;
+        const s16x4_t x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lx + tb + xoff[0]));
+        const s16x4_t x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lx + tb + xoff[1]));
+        const bf16x8_t xv = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+        for (int ky = R & 1; ky < 7; ky += 2) {
+          const int ks = (R - ky) / 2;
+          if (R - ky >= 0 && ks < 8) acc[ky * 7 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xv, gfr[ks], acc[ky * 7 + kx], 0, 0, 0);   // D[channel][co]
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // acc[t]: row i = channel 16*wave + 4*fg + r, column j = co = fi  ->  part[block][co][t][channel]
+  if (fi < 8) {
+    float* dst = a.part + ((int64_t)blockIdx.x * 8 + fi) * (49 * 64) + wave * 16 + fg * 4;
+#pragma unroll
+    for (int t = 0; t < 49; ++t) *reinterpret_cast<f32x4_t*>(dst + t * 64) = acc[t];
+  }
+}
+}  // namespace
+
+// slabs (= blocks) the window weight-gradient kernel writes for this descriptor; 0: it does not qualify
+extern "C" int gan_wgrad_win7_splits(const gan_wgrad_desc* d) {
+  if (!d || d->dtype != GAN_BF16 || d->Cx != 64 || d->N != 8 || d->g_C != 8 || d->ntaps != 49) return 0;
+  if (d->x_sy != 1 || d->x_sx != 1 || d->g_sy != 1 || d->g_sx != 1) return 0;
+  if (d->max_tapoff != (6 * d->x_Wp + 6) * d->Cx) return 0;           // 49 row-major taps from (x_y0, x_x0)
+  { const char* e = getenv("GAN_NO_WIN7"); if (e && atoi(e)) return 0; }
+  const int64_t tiles = (int64_t)d->B * ((d->Ho + TS - 1) / TS) * ((d->Wo + TS - 1) / TS);
+  return (int)(tiles < 256 ? tiles : 256);
+}
+
+int gan_wgrad_win7_launch(const gan_wgrad_desc* d, hipStream_t s) {
+  const int ns = gan_wgrad_win7_splits(d);
+  GAN_CHECK(ns > 0 && d->nsplit == ns, "wgrad: variant 2 needs nsplit = gan_wgrad_win7_splits() = %d, got %d", ns, d->nsplit);
+  GAN_CHECK(d->x && d->g && d->part, "wgrad(7x7 window): null pointer");
+  GAN_CHECK(d->x_y0 >= 0 && d->x_x0 >= 0 && d->Ho - 1 + d->x_y0 + 6 < d->x_Hp && d->Wo - 1 + d->x_x0 + 6 < d->x_Wp,
+            "wgrad(7x7 window): taps reach outside the x allocation");
+  Wg7Args a;
+  a.x = (const char*)d->x; a.g = (const char*)d->g; a.part = d->part;
+  a.B = d->B; a.Ho = d->Ho; a.Wo = d->Wo; a.tiles_x = (d->Wo + TS - 1) / TS; a.tiles_y = (d->Ho + TS - 1) / TS;
+  a.ntiles = d->B * a.tiles_x * a.tiles_y;
+  a.x_Hp = d->x_Hp; a.x_Wp = d->x_Wp; a.x_y0 = d->x_y0; a.x_x0 = d->x_x0;
+  a.g_Hp = d->g_Hp; a.g_Wp = d->g_Wp; a.g_y0 = d->g_y0; a.g_x0 = d->g_x0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)wgrad_win7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG7_LDS) != hipSuccess)
+      return gan_set_error(-2, "wgrad(7x7 window): cannot raise the dynamic LDS limit to %d bytes", WG7_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad_win7_kernel, dim3(ns), dim3(256), WG7_LDS, s, a);
   GAN_LAUNCH_CHECK();
   return 0;
 }

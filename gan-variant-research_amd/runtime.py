@@ -121,7 +121,7 @@ class WgradCall:
     g_sx: int
     part: Optional[torch.Tensor]
     max_tapoff: int = 0
-    variant: int = 0          # 1: range-patch kernel (nsplit = B * splits per image)
+    variant: int = 0          # 1: range-patch kernel (nsplit = B * splits per image); 2: 7x7 window kernel (nsplit = its block count)
 
 
 Op = Callable[[], None]
@@ -290,6 +290,10 @@ class HipOps:
     def wgrad_patch_splits(self, c: WgradCall) -> int:
         """Splits per image the range-patch weight-gradient kernel wants for this call (0: not eligible)."""
         return int(self.lib.gan_wgrad_patch_splits(C.byref(self._wgrad_desc(c))))
+
+    def wgrad_win7_splits(self, c: WgradCall) -> int:
+        """Slabs the 7x7 window weight-gradient kernel writes for this call (0: not eligible); then variant 2, nsplit = this."""
+        return int(self.lib.gan_wgrad_win7_splits(C.byref(self._wgrad_desc(c))))
 
     def conv_wgrad(self, c: WgradCall) -> Op:
         self._keep.append(c)

@@ -83,7 +83,8 @@ typedef struct gan_wgrad_desc {
   int32_t g_Hp, g_Wp, g_C, g_y0, g_x0, g_sy, g_sx;
   float* part;                   /* device fp32 [nsplit][N][ntaps][Cx] */
   int32_t max_tapoff;            /* largest value in tapoff[] (range-patch variant's span check) */
-  int32_t variant;               /* 0: generic kernel, any nsplit; 1: range-patch kernel, nsplit = B * gan_wgrad_patch_splits() */
+  int32_t variant;               /* 0: generic kernel, any nsplit; 1: range-patch kernel, nsplit = B * gan_wgrad_patch_splits();
+                                    2: 7x7 window kernel, nsplit = gan_wgrad_win7_splits() */
 } gan_wgrad_desc;
 
 const char* gan_last_error(void);
@@ -107,6 +108,9 @@ int gan_conv_wgrad(const gan_wgrad_desc* d, void* stream);
  * Cx % 64 == 0, N % 128 == 0, one 128-pixel stage's window span fits LDS); pure host-side predicate for the planner */
 int gan_wgrad_patch_splits(const gan_wgrad_desc* d);
 /* grad[(a*I2 + b)*KK + khw[t]] (+)= sum_s part[s][n][t][c], (a,b) = swap ? (c,n) : (n,c), for n<N_real, c<C_real, khw[t]>=0 */
+/* slabs the 7x7 window weight-gradient kernel writes (0: the descriptor does not qualify: bf16, Cx = 64, N = g_C = 8, 49 row-major taps,
+ * stride 1 -- the weight gradient of the generator's 64 -> 3 channel output convolution) */
+int gan_wgrad_win7_splits(const gan_wgrad_desc* d);
 int gan_wgrad_reduce(const float* part, int nsplit, int N, int ntaps, int Cx, int N_real, int C_real, int swap, int I2,
                      int KK, const int32_t* khw, float* grad, int accumulate, void* stream);
 /* dst[n][t][c] = src[(a*I2 + b)*KK + khw[t]] (0 where n>=N_real, c>=C_real or khw[t]<0); dst dtype GAN_*.

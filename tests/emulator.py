@@ -189,6 +189,14 @@ class EmuOps:
         spi = (256 + c.B * bps - 1) // (c.B * bps)
         return max(1, min(spi, max(1, c.Ho * c.Wo // 256)))
 
+    def wgrad_win7_splits(self, c):
+        """Statement of gan_wgrad_win7_splits (csrc/conv_win7.hip)."""
+        if c.x.dtype != 1 or c.Cx != 64 or c.N != 8 or c.g.C != 8 or c.ntaps != 49 or (c.x_sy, c.x_sx, c.g_sy, c.g_sx) != (1, 1, 1, 1):
+            return 0
+        if c.max_tapoff != (6 * c.x.Wp + 6) * c.Cx:
+            return 0
+        return min(256, c.B * (-(-c.Ho // 16)) * (-(-c.Wo // 16)))
+
     def conv_wgrad(self, c):
         def op():
             x = c.x.padded().float()

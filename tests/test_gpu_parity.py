@@ -35,11 +35,13 @@ def test_conv_7x7_window_kernel_is_taken(geom):
     3->64: first conv forward, output conv's input gradient) and stay correct (run_conv_geometry compares with torch);
     GAN_NO_WIN7=1 would send them back to the generic kernel."""
     ctx = hip_ctx(BF16)
-    seen = []
-    orig = ctx.ops.conv_igemm
+    seen, wg = [], []
+    orig, orig_w = ctx.ops.conv_igemm, ctx.ops.conv_wgrad
     ctx.ops.conv_igemm = lambda c: (seen.append(c.win7), orig(c))[1]
+    ctx.ops.conv_wgrad = lambda c: (wg.append(c.variant), orig_w(c))[1]
     cases.run_conv_geometry(ctx, geom, BF16, B=3)
     assert sum(w is not None for w in seen) == 2, f"forward and input gradient should both run on the 7x7 window kernels: {seen}"
+    assert wg == [2 if geom[0] == 64 else 0], f"weight gradient of the 64->3 layer runs on the window kernel: {wg}"
 
 
 # ---------------------------------------------------------------------------------------------- op twins
