@@ -324,22 +324,29 @@ __global__ __launch_bounds__(256) void bias_part_finalize_kernel(const float* __
 }
 
 // the same sum for many layers in ONE launch: block -> (descriptor, 32-channel group) through first_block
-__global__ __launch_bounds__(256) void bias_finalize_batch_kernel(const gan_bias_part_desc* __restrict__ descs, int n) {
+__global__ __launch_bounds__(1024) void bias_finalize_batch_kernel(const gan_bias_part_desc* __restrict__ descs, int n) {
   int lo = 0, hi = n - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
     if (descs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const gan_bias_part_desc d = descs[lo];
-  const int c = ((int)blockIdx.x - d.first_block) * 32 + (threadIdx.x & 31), k0 = threadIdx.x >> 5;
-  float s = 0.f;
-  if (c < d.C)
-    for (int k = k0; k < d.nparts; k += 8) s += d.part[(int64_t)k * d.C + c];
-  __shared__ float sh[256];
-  sh[threadIdx.x] = s;
+  const int c = ((int)blockIdx.x - d.first_block) * 32 + (threadIdx.x & 31), k0 = threadIdx.x >> 5;   // 32 partial rows in flight per channel
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < d.C) {
+    const float* p = d.part + c;
+    int k = k0;
+    for (; k + 96 < d.nparts; k += 128) {
+      s0 += p[(int64_t)k * d.C]; s1 += p[(int64_t)(k + 32) * d.C]; s2 += p[(int64_t)(k + 64) * d.C]; s3 += p[(int64_t)(k + 96) * d.C];
+    }
+    for (; k < d.nparts; k += 32) s0 += p[(int64_t)k * d.C];
+  }
+  __shared__ float sh[1024];
+  sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (k0 == 0 && c < d.N_real) {
-    for (int k = 1; k < 8; ++k) s += sh[k * 32 + (threadIdx.x & 31)];
+    float s = 0.f;
+    for (int k = 0; k < 32; ++k) s += sh[k * 32 + (threadIdx.x & 31)];
     d.grad[c] = d.accumulate ? d.grad[c] + s : s;
   }
 }
@@ -594,7 +601,7 @@ extern "C" int gan_in_bwd_bias_deferred(const gan_view* x, const float* stats, i
 
 extern "C" int gan_bias_finalize_batch(const gan_bias_part_desc* descs, int n, int total_blocks, void* stream) {
   GAN_CHECK(descs && n > 0 && total_blocks > 0, "bias_finalize_batch: empty batch");
-  hipLaunchKernelGGL(bias_finalize_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs, n);
+  hipLaunchKernelGGL(bias_finalize_batch_kernel, dim3(total_blocks), dim3(1024), 0, (hipStream_t)stream, descs, n);
   GAN_LAUNCH_CHECK();
   return 0;
 }
