@@ -363,9 +363,111 @@ __global__ __launch_bounds__(256, 1) void wgrad_win7_kernel(Wg7Args a) {
 }
 }  // namespace
 
+// ---- the mirror case: weight gradient of the generator's FIRST convolution (3, padded 8, -> 64 channels).  Rows of the MFMA are the 64
+// output channels (wave w owns 16 of them), columns are (tap, input channel): a pixel of X is one 16-byte chunk, so the 16 columns of a
+// transposing read are the 8 channels of pixel P and of pixel P+1 = two horizontally adjacent taps.  28 accumulator tiles per wave
+// (7 tap rows x 4 column pairs, the 8th column of the last pair is padding); X fragments are shared across tap rows as above.
+namespace {
+constexpr int GP64 = 160;                                 // dY pixel pitch in LDS (64 channels = 128 B, padded: see WPITCH)
+constexpr int XW_BYTES = (PW * PW + 8) * 16;
+constexpr int WG7B_LDS = XW_BYTES + TS * TS * GP64;
+
+__global__ __launch_bounds__(256, 2) void wgrad_win7_from3_kernel(Wg7Args a) {
+  __shared__ __attribute__((aligned(16))) char lds[WG7B_LDS];
+  char* lx = lds;
+  char* lg = lds + XW_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fi = lane & 15, fg = lane >> 4, q = fi >> 2, p = fi & 3;
+  f32x4_t acc[7][4];
+#pragma unroll
+  for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) acc[ky][pr] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int per_img = a.tiles_x * a.tiles_y;
+  int xoff[2], goff[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = fg >> 1, xx = h * 8 + (fg & 1) * 4 + q;           // the K-index -> pixel bijection of wgrad_win7_kernel
+    xoff[h] = (r * PW + xx) * 16 + p * 8;
+    goff[h] = (r * TS + xx) * GP64 + (wave * 16 + p * 4) * 2;
+  }
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int b = tile / per_img, t2 = tile - b * per_img;
+    const int oy0 = (t2 / a.tiles_x) * TS, ox0 = (t2 % a.tiles_x) * TS;
+    __syncthreads();
+    {
+      const int ay0 = oy0 + a.x_y0, ax0 = ox0 + a.x_x0;
+      const char* img = a.x + (int64_t)b * a.x_Hp * a.x_Wp * 16;
+      u32x4_t sx[2];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int px_ = tid + it * 256;
+        const int py = px_ / PW, px = px_ - py * PW;
+        const int ay = ay0 + py, ax = ax0 + px;
+        const bool ok = px_ < PW * PW && ay >= 0 && ay < a.x_Hp && ax >= 0 && ax < a.x_Wp;
+        u32x4_t v = *reinterpret_cast<const u32x4_t*>(img + (ok ? ((int64_t)ay * a.x_Wp + ax) * 16 : 0));
+        if (!ok) v = u32x4_t{0u, 0u, 0u, 0u};
+        sx[it] = v;
+      }
+      // dY tile: 256 pixels x 8 chunks; one pixel per thread, 8 loads in flight
+      const int gy = oy0 + (tid >> 4), gx = ox0 + (tid & 15);
+      const bool gok = gy < a.Ho && gx < a.Wo;
+      const char* gp = a.g + (gok ? (((int64_t)b * a.g_Hp + gy + a.g_y0) * a.g_Wp + gx + a.g_x0) * 128 : 0);
+      u32x4_t sg[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { sg[c] = *reinterpret_cast<const u32x4_t*>(gp + c * 16); if (!gok) sg[c] = u32x4_t{0u, 0u, 0u, 0u}; }
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+        if (tid + it * 256 < PW * PW + 8) *reinterpret_cast<u32x4_t*>(lx + (tid + it * 256) * 16) = sx[it];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) *reinterpret_cast<u32x4_t*>(lg + tid * GP64 + c * 16) = sg[c];
+    }
+    __syncthreads();
+    bf16x8_t gfr[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const s16x4_t g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lg + ks * (2 * TS * GP64) + goff[0]));
+      const s16x4_t g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lg + ks * (2 * TS * GP64) + goff[1]));
+      gfr[ks] = bf16x8_t{g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+    }
+#pragma unroll
+    for (int R = 0; R <= 20; ++R) {
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) {
+        const int tb = (R * PW + 2 * pr) * 16;
+        const s16x4_t x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lx + tb + xoff[0]));
+        const s16x4_t x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lx + tb + xoff[1]));
+        const bf16x8_t xv = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+        for (int ky = R & 1; ky < 7; ky += 2) {
+          const int ks = (R - ky) / 2;
+          if (R - ky >= 0 && ks < 8) acc[ky][pr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfr[ks], xv, acc[ky][pr], 0, 0, 0);   // D[co][(tap, ci)]
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // acc[ky][pr]: row co = 16*wave + 4*fg + r, column fi -> tap (ky, 2*pr + (fi>>3)), input channel fi&7  ->  part[block][co][tap][ci]
+  const int kxo = fi >> 3, ci = fi & 7;
+  float* dst = a.part + ((int64_t)blockIdx.x * 64 + wave * 16 + fg * 4) * (49 * 8) + ci;
+#pragma unroll
+  for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      const int kx = 2 * pr + kxo;
+      if (kx < 7) {
+        float* o = dst + (ky * 7 + kx) * 8;
+        o[0] = acc[ky][pr].x; o[49 * 8] = acc[ky][pr].y; o[2 * 49 * 8] = acc[ky][pr].z; o[3 * 49 * 8] = acc[ky][pr].w;
+      }
+    }
+}
+}  // namespace
+
 // slabs (= blocks) the window weight-gradient kernel writes for this descriptor; 0: it does not qualify
 extern "C" int gan_wgrad_win7_splits(const gan_wgrad_desc* d) {
-  if (!d || d->dtype != GAN_BF16 || d->Cx != 64 || d->N != 8 || d->g_C != 8 || d->ntaps != 49) return 0;
+  if (!d || d->dtype != GAN_BF16 || d->ntaps != 49) return 0;
+  const bool to3 = d->Cx == 64 && d->N == 8 && d->g_C == 8, from3 = d->Cx == 8 && d->N == 64 && d->g_C == 64;
+  if (!to3 && !from3) return 0;
   if (d->x_sy != 1 || d->x_sx != 1 || d->g_sy != 1 || d->g_sx != 1) return 0;
   if (d->max_tapoff != (6 * d->x_Wp + 6) * d->Cx) return 0;           // 49 row-major taps from (x_y0, x_x0)
   { const char* e = getenv("GAN_NO_WIN7"); if (e && atoi(e)) return 0; }
@@ -385,6 +487,11 @@ int gan_wgrad_win7_launch(const gan_wgrad_desc* d, hipStream_t s) {
   a.ntiles = d->B * a.tiles_x * a.tiles_y;
   a.x_Hp = d->x_Hp; a.x_Wp = d->x_Wp; a.x_y0 = d->x_y0; a.x_x0 = d->x_x0;
   a.g_Hp = d->g_Hp; a.g_Wp = d->g_Wp; a.g_y0 = d->g_y0; a.g_x0 = d->g_x0;
+  if (d->Cx == 8) {
+    hipLaunchKernelGGL(wgrad_win7_from3_kernel, dim3(ns), dim3(256), 0, s, a);
+    GAN_LAUNCH_CHECK();
+    return 0;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)wgrad_win7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG7_LDS) != hipSuccess)

@@ -108,8 +108,8 @@ int gan_conv_wgrad(const gan_wgrad_desc* d, void* stream);
  * Cx % 64 == 0, N % 128 == 0, one 128-pixel stage's window span fits LDS); pure host-side predicate for the planner */
 int gan_wgrad_patch_splits(const gan_wgrad_desc* d);
 /* grad[(a*I2 + b)*KK + khw[t]] (+)= sum_s part[s][n][t][c], (a,b) = swap ? (c,n) : (n,c), for n<N_real, c<C_real, khw[t]>=0 */
-/* slabs the 7x7 window weight-gradient kernel writes (0: the descriptor does not qualify: bf16, Cx = 64, N = g_C = 8, 49 row-major taps,
- * stride 1 -- the weight gradient of the generator's 64 -> 3 channel output convolution) */
+/* slabs the 7x7 window weight-gradient kernels write (0: the descriptor does not qualify: bf16, 49 row-major taps, stride 1, and
+ * Cx = 64, N = g_C = 8 -- the generator's 64 -> 3 channel output convolution -- or Cx = 8, N = g_C = 64 -- its 3 -> 64 first one) */
 int gan_wgrad_win7_splits(const gan_wgrad_desc* d);
 int gan_wgrad_reduce(const float* part, int nsplit, int N, int ntaps, int Cx, int N_real, int C_real, int swap, int I2,
                      int KK, const int32_t* khw, float* grad, int accumulate, void* stream);

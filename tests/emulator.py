@@ -191,7 +191,8 @@ class EmuOps:
 
     def wgrad_win7_splits(self, c):
         """Statement of gan_wgrad_win7_splits (csrc/conv_win7.hip)."""
-        if c.x.dtype != 1 or c.Cx != 64 or c.N != 8 or c.g.C != 8 or c.ntaps != 49 or (c.x_sy, c.x_sx, c.g_sy, c.g_sx) != (1, 1, 1, 1):
+        to3, from3 = (c.Cx, c.N, c.g.C) == (64, 8, 8), (c.Cx, c.N, c.g.C) == (8, 64, 64)
+        if c.x.dtype != 1 or not (to3 or from3) or c.ntaps != 49 or (c.x_sy, c.x_sx, c.g_sy, c.g_sx) != (1, 1, 1, 1):
             return 0
         if c.max_tapoff != (6 * c.x.Wp + 6) * c.Cx:
             return 0
