@@ -59,13 +59,23 @@ def dominant_kernel_roofline(trainer, iters=10):
     flops = sum(2.0 * o.conv.B * o.conv.Ho * o.conv.Wo * o.conv.Nst * o.conv.Cin * o.conv.ntaps for o in calls)
 
     def timed(ops, n):
+        """ms per pass over `ops`, between two HIP events on the caller's stream; launches that the programs put on the trainer's
+        other streams (discriminator, weight-gradient side streams) are joined into that stream before the closing event."""
+        main = torch.cuda.current_stream()
         for o in ops:
             o()
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+        for s in trainer.side_streams():
+            s.wait_event(e0)
         for _ in range(n):
             for o in ops:
                 o()
+        for s in trainer.side_streams():
+            ev = torch.cuda.Event()
+            ev.record(s)
+            main.wait_event(ev)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
@@ -77,6 +87,14 @@ def dominant_kernel_roofline(trainer, iters=10):
     res_flops = 2.0 * x.B * y.H * y.W * conv.cout * conv.cin * 9   # x.B = 2 x batch while the identity pass rides in the generator pass
     peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
     ach = flops / (ms * 1e-3) / 1e12
+    # the HBM-bound side of the path: every InstanceNorm forward / backward launch of the step, replayed the same way;
+    # achieved = algorithmic bytes (each operand tensor once) / elapsed
+    norm = [o for p in progs if p is not None for o in p.ops if getattr(o, "hbm_bytes", None)]
+    norm_ms = timed(norm, iters)
+    norm_bytes = float(sum(o.hbm_bytes for o in norm))
+    trainer.norm_hbm = {"bound": "hbm", "achieved": round(norm_bytes / (norm_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(norm_bytes / (norm_ms * 1e-3) / 8e12, 4), "kernel": "in_apply / in_bwd_* (InstanceNorm forward and backward)",
+                        "launches_per_step": len(norm), "bytes_per_step": norm_bytes, "ms_per_step": round(norm_ms, 4)}
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": pmc_traffic("conv_patch_kernel") if bf16 else None,
             "kernel": "conv_patch_kernel" if bf16 else "conv_igemm_kernel<float,...>",
@@ -222,6 +240,7 @@ def main():
             "last_losses": last,
         }
         out["roofline"] = dominant_kernel_roofline(tr)
+        out["norm_hbm"] = getattr(tr, "norm_hbm", None)      # the HBM-bound kernels of the path, measured the same way
         print(f"[bench] gpu: {ips:.1f} images/s, {dt / args.steps * 1e3:.2f} ms/step; roofline {out['roofline']['achieved']} TFLOP/s", file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:     # the CPU baseline is reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(args.size)

@@ -418,6 +418,16 @@ class CutTrainer:
         for k, val in m.items():
             setattr(self, k, val)
 
+    def side_streams(self):
+        """Every torch stream other than the caller's current one that this trainer's programs launch on."""
+        out = []
+        for o in (self.ops, self.opsD):
+            for h in (o, getattr(o, "_side", None)):
+                ts = getattr(h, "torch_stream", None) if h is not None else None
+                if ts is not None and ts not in out:
+                    out.append(ts)
+        return out
+
     def _device_sync(self):
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)

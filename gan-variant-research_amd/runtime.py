@@ -333,15 +333,23 @@ class HipOps:
     def in_stats(self, x: View, eps, stats, ws) -> Op:
         return self._call("gan_in_stats", self._v(x), C.c_float(eps), self._p(stats), self._p(ws), self._s())
 
+    @staticmethod
+    def _hbm(op: Op, x: View, ntensors: int) -> Op:
+        """Algorithmic HBM bytes of an HBM-bound launch (every operand tensor read or written once), for bench.py."""
+        op.hbm_bytes = ntensors * x.B * x.H * x.W * x.C * (4 if x.dtype == F32 else 2)
+        return op
+
     def in_apply(self, x: View, stats, act, residual: Optional[View], y: View, halo_mode) -> Op:
-        return self._call("gan_in_apply", self._v(x), self._p(stats), act, self._v(residual), self._v(y), halo_mode, self._s())
+        return self._hbm(self._call("gan_in_apply", self._v(x), self._p(stats), act, self._v(residual), self._v(y), halo_mode, self._s()),
+                         x, 2 + (residual is not None))
 
     def in_bwd(self, x: View, stats, act, gy: View, fold, g2: Optional[View], dx: View, ws) -> Op:
-        return self._call("gan_in_bwd", self._v(x), self._p(stats), act, self._v(gy), int(fold), self._v(g2), self._v(dx), self._p(ws), self._s())
+        return self._hbm(self._call("gan_in_bwd", self._v(x), self._p(stats), act, self._v(gy), int(fold), self._v(g2), self._v(dx), self._p(ws), self._s()),
+                         x, 3 + (g2 is not None))
 
     def in_bwd_bias(self, x: View, stats, act, gy: View, fold, g2: Optional[View], dx: View, ws, bias_grad, bias_n, accumulate) -> Op:
-        return self._call("gan_in_bwd_bias", self._v(x), self._p(stats), act, self._v(gy), int(fold), self._v(g2), self._v(dx), self._p(ws),
-                          self._p(bias_grad), bias_n, int(accumulate), self._s())
+        return self._hbm(self._call("gan_in_bwd_bias", self._v(x), self._p(stats), act, self._v(gy), int(fold), self._v(g2), self._v(dx), self._p(ws),
+                                    self._p(bias_grad), bias_n, int(accumulate), self._s()), x, 3 + (g2 is not None))
 
     def in_bwd_bias_parts(self, x: View) -> int:
         n = int(self.lib.gan_in_bwd_bias_parts(self._v(x)))
@@ -351,8 +359,8 @@ class HipOps:
 
     def in_bwd_bias_deferred(self, x: View, stats, act, gy: View, fold, g2: Optional[View], dx: View, ws, bias_part) -> Op:
         assert bias_part.dtype == torch.float32 and bias_part.numel() >= self.in_bwd_bias_parts(x) * x.C
-        return self._call("gan_in_bwd_bias_deferred", self._v(x), self._p(stats), act, self._v(gy), int(fold), self._v(g2), self._v(dx), self._p(ws),
-                          self._p(bias_part), self._s())
+        return self._hbm(self._call("gan_in_bwd_bias_deferred", self._v(x), self._p(stats), act, self._v(gy), int(fold), self._v(g2), self._v(dx),
+                                    self._p(ws), self._p(bias_part), self._s()), x, 3 + (g2 is not None))
 
     def bias_finalize_batch(self, items) -> Op:
         """items: (part, nparts, C, grad, N_real, accumulate) per layer -> one launch."""
