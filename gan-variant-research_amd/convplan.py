@@ -88,6 +88,36 @@ class _Pack:
         return max((dy * wp + dx) * self.cred for dy, dx, _ in self.taps)
 
 
+class _PairPack(_Pack):
+    """The two x-phases (rx = 0, 1) of one phase row of a transposed convolution / strided input gradient as ONE launch, for layers
+    with 64 output channels: output pixels (2a+ry, 2b) and (2a+ry, 2b+1) are neighbours in memory, so the pair is a 128-channel
+    "super-pixel" and the launch is a stride-1 convolution with N = 128 over the union of the two phases' taps -- wide enough for the
+    range-patch kernel, which the 64-wide phases were not (they ran on the generic kernel at 160-400 TFLOP/s).  Rows 0..63 of the
+    packed weight hold phase rx = 0, rows 64..127 phase rx = 1, zero where a phase does not use a tap of the union."""
+
+    def __init__(self, ctx: Ctx, pa: _Pack, pb: _Pack):
+        assert pa.phase[0] == pb.phase[0] and pa.dmin[0] == pb.dmin[0] and pa.n_real == pb.n_real == 64
+        dmy, dmx = pa.dmin[0], min(pa.dmin[1], pb.dmin[1])
+        abs_taps = lambda pk: {(dy + pk.dmin[0], dx + pk.dmin[1]): kidx for dy, dx, kidx in pk.taps}
+        ta, tb = abs_taps(pa), abs_taps(pb)
+        union = sorted(set(ta) | set(tb))
+        super().__init__(ctx, [(dy - dmy, dx - dmx, ta.get((dy, dx), -1)) for dy, dx in union], 128, pa.c_real, pa.swap, pa.i2, pa.kk)
+        self.n_half = pa.n_real
+        pad = [-1] * (self.ntaps - len(union))
+        self.khw_halves = [ctx.i32([ta.get(t, -1) for t in union] + pad), ctx.i32([tb.get(t, -1) for t in union] + pad)]
+        self.dmin, self.dmax = (dmy, dmx), (max(pa.dmax[0], pb.dmax[0]), max(pa.dmax[1], pb.dmax[1]))
+        self.phase_row = pa.phase[0]
+
+    def pack_ops(self, master: torch.Tensor):
+        out, half = [], 64 * self.ntaps * self.cred       # 64 rows = four 16-row fragment groups: the same element count in both layouts
+        for buf, layout in ((self._w, 0), (self._wf, 1)):
+            if buf is not None:
+                for h, khw in enumerate(self.khw_halves):
+                    out.append(self.ctx.ops.pack_weight(master, buf[h * half:(h + 1) * half], self.ctx.dtype, 64, self.ntaps, self.cred, self.n_half,
+                                                        self.c_real, self.swap, self.i2, self.kk, khw, layout))
+        return out
+
+
 def _phase_taps(k: int, p: int, r: int):
     """Transposed-conv / strided-dgrad taps of output parity r: [(kh, d)] with source index a + d."""
     return [(kh, (r + p - kh) // 2) for kh in range(k) if (r + p - kh) % 2 == 0]
@@ -134,6 +164,8 @@ class ConvLayer:
             self.bias_k = torch.zeros(_nw(self.cout), dtype=torch.float32, device=ctx.device)
         self.wg_khw = ctx.i32([t[2] for t in alltaps])
         self._wg_tapoff = {}
+        self._pairs = {}
+        self.bias_pair = None     # [bias | bias] for paired phases (allocated with the first paired plan)
 
     def _phase_packs(self, n_real, c_real, i2):
         """Four sub-pixel phases (ry, rx); index [ry*2+rx] -> (_Pack, dmin_y, dmin_x)."""
@@ -155,6 +187,9 @@ class ConvLayer:
         out = [op for pk in self.packs for op in pk.pack_ops(self.weight)]
         if self.bias_k is not self.bias:
             out.append(self.ctx.ops.pack_weight(self.bias, self.bias_k, F32, self.bias_k.numel(), 1, 1, self.cout, 1, False, 1, 1, self._one))
+        if self.bias_pair is not None:
+            for h in range(2):
+                out.append(self.ctx.ops.pack_weight(self.bias, self.bias_pair[64 * h:64 * h + 64], F32, 64, 1, 1, self.cout, 1, False, 1, 1, self._one))
         return out
 
     # ------------------------------------------------------------------ forward
@@ -181,10 +216,34 @@ class ConvLayer:
         assert (y.H, y.W) == (2 * x.H, 2 * x.W)
         return self._phased(self.fwd_packs, x, y, act, self.bias_k if use_bias else None, mask)
 
+    def _pair_packs(self, packs):
+        """Lazily built _PairPack per phase row (see there); None when the layer does not qualify."""
+        key = id(packs)
+        if key not in self._pairs:
+            ok = (self.ctx.dtype == BF16 and packs[0].n_real == 64 and packs[0].cred % 64 == 0 and not os.environ.get("GAN_NO_PHASE_PAIRS"))
+            self._pairs[key] = [_PairPack(self.ctx, packs[2 * ry], packs[2 * ry + 1]) for ry in range(2)] if ok else None
+            if ok:
+                self.packs += self._pairs[key]
+        return self._pairs[key]
+
     def _phased(self, packs, src: View, dst: View, act, bias, mask):
         """dst[2a+r] = sum_taps src[a + d] * w: used by ConvTranspose2d forward and by the strided conv's input gradient."""
         ops, out = self.ctx.ops, []
         gh, gw = dst.H // 2, dst.W // 2
+        pairs = self._pair_packs(packs) if (dst.halo == 0 and mask is None and dst.C == 64) else None
+        if pairs is not None:
+            # the destination as rows of 128-channel super-pixels (same storage)
+            sup = View(dst.t, dst.B, dst.H, gw, 128, 0, dst.dtype)
+            if bias is not None and self.bias_pair is None:
+                self.bias_pair = torch.zeros(128, dtype=torch.float32, device=self.ctx.device)
+            calls = []
+            for pk in pairs:
+                (dmy, dmx), (dxy, dxx) = pk.dmin, pk.dmax
+                assert src.halo + dmy >= 0 and src.halo + dmx >= 0 and gh - 1 + dxy <= src.H - 1 + src.halo and gw - 1 + dxx <= src.W - 1 + src.halo
+                calls.append(pk.finalize(ConvCall(src.B, gh, gw, pk.cred, pk.ntaps, 128, 128, src, src.halo + dmy, src.halo + dmx, 1, 1, pk.tapoff(src.Wp), None,
+                                                  self.bias_pair if bias is not None else None, sup, pk.phase_row, 0, 2, 1, act, None, 0, 0, pk.max_tapoff(src.Wp))))
+            if all(c.w_frag for c in calls):          # both rows on the range-patch kernel, otherwise keep the four single phases
+                return [ops.conv_igemm(c) for c in calls]
         for pk in packs:
             (ry, rx), (dmy, dmx), (dxy, dxx) = pk.phase, pk.dmin, pk.dmax
             assert src.halo + dmy >= 0 and src.halo + dmx >= 0, "source halo too small (top/left)"

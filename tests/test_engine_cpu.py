@@ -18,7 +18,7 @@ def test_conv_geometry(geom, dtype):
     cases.run_conv_geometry(Ctx(EmuOps(), "cpu", dtype), geom, dtype)
 
 
-@pytest.mark.parametrize("geom", [cases.GEOMS[8], cases.GEOMS[10], cases.GEOMS[13]])
+@pytest.mark.parametrize("geom", [cases.GEOMS[8], cases.GEOMS[9], cases.GEOMS[10], cases.GEOMS[11], cases.GEOMS[13]])
 def test_conv_geometry_fragment_major(geom):
     """Full-width bf16 layers take the range-patch kernel: fragment-major weight copies, checked through the emulator."""
     ctx = Ctx(EmuOps(), "cpu", BF16)
