@@ -56,7 +56,7 @@ def dominant_kernel_roofline(trainer, iters=10):
     bf16 = trainer.amp.enabled
     progs = [trainer.prog_gfwd, trainer.prog_d_compute, trainer.prog_d_update, trainer.prog_g_features, trainer.prog_g_adversarial, trainer.prog_g_features_bwd, trainer.prog_g_compute, trainer.prog_g_identity, trainer.prog_g_update]
     calls = [o for p in progs if p is not None for o in p.ops if getattr(o, "conv", None) is not None and (o.conv.w_frag or not bf16)]
-    flops = sum(2.0 * o.conv.B * o.conv.Ho * o.conv.Wo * o.conv.Nst * o.conv.Cin * o.conv.ntaps for o in calls)
+    flops = sum(2.0 * o.conv.B * o.conv.Ho * o.conv.Wo * o.conv.Nst * o.conv.Cin * o.conv.ntaps * o.conv.flop_scale for o in calls)
 
     def timed(ops, n):
         """ms per pass over `ops`, between two HIP events on the caller's stream; launches that the programs put on the trainer's

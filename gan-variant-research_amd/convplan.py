@@ -243,6 +243,8 @@ class ConvLayer:
                 calls.append(pk.finalize(ConvCall(src.B, gh, gw, pk.cred, pk.ntaps, 128, 128, src, src.halo + dmy, src.halo + dmx, 1, 1, pk.tapoff(src.Wp), None,
                                                   self.bias_pair if bias is not None else None, sup, pk.phase_row, 0, 2, 1, act, None, 0, 0, pk.max_tapoff(src.Wp))))
             if all(c.w_frag for c in calls):          # both rows on the range-patch kernel, otherwise keep the four single phases
+                for c, pk in zip(calls, pairs):           # useful share of the launched FLOPs: taps each half really has / (2 x union)
+                    c.flop_scale = sum(int(k) >= 0 for khw in pk.khw_halves for k in khw.tolist()) / (2.0 * len(pk.taps))
                 return [ops.conv_igemm(c) for c in calls]
         for pk in packs:
             (ry, rx), (dmy, dmx), (dxy, dxx) = pk.phase, pk.dmin, pk.dmax

@@ -96,6 +96,7 @@ class ConvCall:
     w_frag: bool = False      # w is the fragment-major copy (range-patch kernel)
     stats: Optional[torch.Tensor] = None   # InstanceNorm partials written by the epilogue (see HipOps.conv_stats_parts)
     win7: Optional[tuple] = None           # (ty0, tx0): run by the 7x7 window kernel, taps row-major from that position (w_layout 2)
+    flop_scale: float = 1.0                # algorithmic / launched FLOPs (paired phases multiply by zero blocks: 0.75); bench.py prices with it
 
 
 @dataclass
