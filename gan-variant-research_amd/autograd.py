@@ -176,11 +176,33 @@ class _GenBridge(_Bridge):
         B, C, H, W = x.shape
         assert C == self.net.in_c
         last = None if feat_ids is None else max(feat_ids)
-        s = self._lease((B, H, W, last), lambda: self._make_slot(B, H, W, last))
+        # Forward-only calls of a module with `use_graph = True` replay the pass as ONE hipGraph launch: at small batch the ~110
+        # launches of a generator pass cost more host time than GPU time.  Ops bake the stream that is current when they are built,
+        # so a graph slot is planned, warmed up and captured on a stream of its own; the replay runs on the caller's stream.
+        use_graph = (not keep) and feat_ids is None and getattr(self.module, "use_graph", False) and getattr(self.ctx.ops, "is_hip", False)
+
+        def make_graph_slot():
+            gs = torch.cuda.Stream(self.device)
+            with torch.cuda.stream(gs):
+                slot = self._make_slot(B, H, W, last)
+            slot.gstream, slot.graph = gs, None
+            return slot
+        s = self._lease((B, H, W, last, "graph"), make_graph_slot) if use_graph else self._lease((B, H, W, last), lambda: self._make_slot(B, H, W, last))
         try:
             self._sync_weights()
             s.xin.copy_(x)
-            s.fwd.run()
+            if use_graph:
+                if s.graph is None:
+                    s.gstream.wait_stream(torch.cuda.current_stream(self.device))
+                    with torch.cuda.stream(s.gstream):
+                        s.fwd.run()                      # eager once: first-launch work (function attributes) must not happen under capture
+                    torch.cuda.synchronize(self.device)
+                    s.graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(s.graph, stream=s.gstream):
+                        s.fwd.run()
+                s.graph.replay()
+            else:
+                s.fwd.run()
             if feat_ids is None:
                 outs = (s.out.clone(),)
             else:

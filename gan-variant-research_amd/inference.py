@@ -36,7 +36,7 @@ def pick_state_dict(ckpt: Dict) -> Dict[str, torch.Tensor]:
     raise KeyError(f"no generator state_dict in checkpoint (keys: {list(ckpt)[:10]})")
 
 
-def load_generator(ckpt_path: str, device: str = "cuda", ngf: int = 64, n_blocks: int = 9, bf16: bool = True) -> ResNetGenerator:
+def load_generator(ckpt_path: str, device: str = "cuda", ngf: int = 64, n_blocks: int = 9, bf16: bool = True, use_graph: bool = False) -> ResNetGenerator:
     """generate_folder.py:189-205.  The file is read with weights_only=True (tensors and plain containers; nothing is unpickled)."""
     ckpt = torch.load(ckpt_path, map_location=device, weights_only=True)
     if not isinstance(ckpt, dict):
@@ -49,6 +49,9 @@ def load_generator(ckpt_path: str, device: str = "cuda", ngf: int = 64, n_blocks
     for p in G.parameters():
         p.requires_grad_(False)
     G.compute_dtype = BF16 if bf16 else F32      # the reference runs inference under autocast (:237)
+    # use_graph: forward-only passes replay one hipGraph per input shape (autograd._GenBridge.forward).  Off by default: on ROCm 7.2 the
+    # replay of the ~110-node graph is slower than the eager launches at small batch (1.70 vs 1.14 ms at B=1, equal at B=16; tools/bench_infer.py)
+    G.use_graph = use_graph
     return G
 
 

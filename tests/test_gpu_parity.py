@@ -332,6 +332,26 @@ def test_optional_discriminators_hip(monkeypatch, tag):
     optional_cases(torch.device(DEV), 5e-4, tags=(tag,))
 
 
+def test_inference_graph_replay_equals_eager():
+    """Forward-only passes of a module with use_graph=True are captured once per input shape and replayed as one hipGraph launch:
+    same bits as the eager launches, also after the weights changed (the graph reads the refreshed operand copies)."""
+    from gan_variant_research_amd import cut as C, inference as I
+    C.set_seed(1)
+    G = C.ResNetGenerator(3, 3, 16, 3).to(DEV).eval()
+    G.compute_dtype = BF16
+    x = (torch.rand(2, 3, 64, 64) * 2 - 1).to(DEV)
+    eager = I.stylize(G, x)
+    G.use_graph = True
+    first, replay = I.stylize(G, x), I.stylize(G, x)
+    assert torch.equal(eager, first) and torch.equal(eager, replay)
+    with torch.no_grad():
+        for p_ in G.parameters():
+            p_.mul_(1.01)
+    after = I.stylize(G, x)
+    G.use_graph = False
+    assert torch.equal(after, I.stylize(G, x)) and not torch.equal(after, eager)
+
+
 def test_loss_callables_hip(monkeypatch):
     from gan_variant_research_amd import losses as L
     from tests.test_autograd_bridge import loss_cases
