@@ -134,11 +134,14 @@ class _GenBridge(_Bridge):
     def _make_net(self):
         m = self.module
         in_c, out_c = getattr(m, "in_c", getattr(m, "input_nc", 3)), getattr(m, "out_c", getattr(m, "output_nc", 3))
-        return GeneratorNet(self.ctx, self.params, self.grads, self.style, m.n_blocks, m.ngf, in_c, out_c, need_input_grad=True)
+        self.reflect = getattr(m, "padding_type", "reflect") == "reflect"
+        act = _lib.ACT_LRELU if getattr(m, "activation", "relu") == "leaky_relu" else _lib.ACT_RELU
+        return GeneratorNet(self.ctx, self.params, self.grads, self.style, m.n_blocks, m.ngf, in_c, out_c, need_input_grad=True,
+                            reflect=self.reflect, block_act=act)
 
     def touched(self, last: Optional[int]) -> List[bool]:
         """Which parameters a pass that stops after numbered activation `last` (None: full) has gradients for."""
-        k_init, k_down, k_blk, k_up, k_out = generator_keys(self.style, self.net.n_blocks)
+        k_init, k_down, k_blk, k_up, k_out = generator_keys(self.style, self.net.n_blocks, reflect=self.reflect)
         nb = self.net.n_blocks
         full = last is None
         last = self.net.n_layers - 1 if full else last
@@ -249,7 +252,7 @@ class _GenBridge(_Bridge):
             prog.add(gp.bwd_program(g_img, False, None, hooks=hooks, accumulate=False, need_input_grad=need_x))
             if need_x:
                 tmp = ctx.view(gp.B, gp.H, gp.W, gp.x0.C, 0)
-                prog.add(ops.fold_add(None, gp.g_input, True, tmp))      # reflection-pad gradient of the first layer
+                prog.add(ops.fold_add(None, gp.g_input, gp.g_input_fold, tmp))      # reflection-pad gradient of the first layer
                 prog.add(ops.view_to_nchw(tmp, self.net.in_c, s.gx))
             s.bwd[key] = prog
             self._repack, self._packed_version = None, None   # planning may have allocated gradient-order operand copies

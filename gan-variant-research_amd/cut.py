@@ -47,10 +47,14 @@ def _slot(n):
 
 
 class _ResBlockParams(nn.Module):
-    def __init__(self, c):
+    def __init__(self, c, reflect=True):
         super().__init__()
-        seq = _slot(7)
-        seq[1], seq[5] = nn.Conv2d(c, c, 3), nn.Conv2d(c, c, 3)
+        if reflect:      # [pad, conv, norm, act, pad, conv, norm] (generator_resnet_attn.py:24-52)
+            seq = _slot(7)
+            seq[1], seq[5] = nn.Conv2d(c, c, 3), nn.Conv2d(c, c, 3)
+        else:            # zero padding lives in the convolutions: [conv, norm, act, conv, norm]
+            seq = _slot(5)
+            seq[0], seq[3] = nn.Conv2d(c, c, 3, padding=1), nn.Conv2d(c, c, 3, padding=1)
         self.conv_block = nn.Sequential(*seq)
 
 
@@ -61,19 +65,28 @@ class ResNetGenerator(nn.Module):
                  activation="relu", use_attention=True, attn_layers=(3, 7), use_channel_attn=True, channel_attn_layers=(5,),
                  use_style_dropout=True, alpha_min=0.4, alpha_max=0.9):
         super().__init__()
-        if (padding_type, norm, activation, n_downsampling) != ("reflect", "instance", "relu", 2):
-            raise NotImplementedError("MI355X path implements the baseline config: reflect padding, instance norm, ReLU, 2 downsamplings")
+        if padding_type not in ("reflect", "zero") or activation not in ("relu", "leaky_relu") or norm != "instance" or n_downsampling != 2:
+            raise NotImplementedError("MI355X path: padding_type 'reflect' | 'zero', activation 'relu' | 'leaky_relu', instance norm, 2 downsamplings "
+                                      "(not built: replicate padding, batch / no norm, other depths)")
         self.input_nc, self.output_nc, self.ngf, self.n_blocks = input_nc, output_nc, ngf, n_blocks
-        s = _slot(4); s[1] = nn.Conv2d(input_nc, ngf, 7)
+        self.padding_type, self.activation = padding_type, activation
+        rf = padding_type == "reflect"
+        if rf:
+            s = _slot(4); s[1] = nn.Conv2d(input_nc, ngf, 7)
+        else:            # no pad module in front (generator_resnet_attn.py:110-116): the conv sits at index 0
+            s = _slot(3); s[0] = nn.Conv2d(input_nc, ngf, 7, padding=3)
         self.initial = nn.Sequential(*s)
         s = _slot(6); s[0], s[3] = nn.Conv2d(ngf, 2 * ngf, 3, stride=2, padding=1), nn.Conv2d(2 * ngf, 4 * ngf, 3, stride=2, padding=1)
         self.downsample = nn.Sequential(*s)
-        self.res_blocks = nn.ModuleList([_ResBlockParams(4 * ngf) for _ in range(n_blocks)])
+        self.res_blocks = nn.ModuleList([_ResBlockParams(4 * ngf, rf) for _ in range(n_blocks)])
         s = _slot(6)
         s[0] = nn.ConvTranspose2d(4 * ngf, 2 * ngf, 3, stride=2, padding=1, output_padding=1)
         s[3] = nn.ConvTranspose2d(2 * ngf, ngf, 3, stride=2, padding=1, output_padding=1)
         self.upsample = nn.Sequential(*s)
-        s = _slot(3); s[1] = nn.Conv2d(ngf, output_nc, 7)
+        if rf:
+            s = _slot(3); s[1] = nn.Conv2d(ngf, output_nc, 7)
+        else:
+            s = _slot(2); s[0] = nn.Conv2d(ngf, output_nc, 7, padding=3)
         self.output = nn.Sequential(*s)
         self.compute_dtype = F32          # BF16: bf16 operands, fp32 accumulation (throughput mode)
 
@@ -336,6 +349,9 @@ class CutTrainer:
         self.policy = config["diffaugment"].get("policy", ["color", "translation", "cutout"]) if config["diffaugment"].get("enable", False) else None
         self.aug = DiffAugment(self.policy) if self.policy is not None else None
         self.generator, self.discriminator = generator, discriminator
+        if getattr(generator, "padding_type", "reflect") != "reflect" or getattr(generator, "activation", "relu") != "relu":
+            raise NotImplementedError("the fused CutTrainer runs the reference configuration (reflect padding, ReLU blocks); "
+                                      "module_step.train_step drives the other generator variants on the same kernels")
         if getattr(discriminator, "num_scales", 1) != 1 or getattr(discriminator, "use_spectral_norm", False):
             raise NotImplementedError("the fused CutTrainer runs the reference configuration (one discriminator scale, no spectral norm); "
                                       "module_step.train_step drives the optional discriminator variants on the same kernels")

@@ -21,12 +21,14 @@ from .runtime import IN_WS_CHUNKS, Ctx, Program, View, cpad
 IN_EPS = 1e-5
 
 
-def generator_keys(style: str, n_blocks: int, n_down: int = 2):
-    """state_dict key prefixes in execution order: (init, [down], [(blk_a, blk_b)], [up], out)."""
+def generator_keys(style: str, n_blocks: int, n_down: int = 2, reflect: bool = True):
+    """state_dict key prefixes in execution order: (init, [down], [(blk_a, blk_b)], [up], out).  With zero padding the
+    reference builds no pad modules (generator_resnet_attn.py:24-30,43-46,110-113,157-160), which shifts the Sequential indices."""
     if style == "cut":
-        return ("initial.1", [f"downsample.{3*i}" for i in range(n_down)],
-                [(f"res_blocks.{b}.conv_block.1", f"res_blocks.{b}.conv_block.5") for b in range(n_blocks)],
-                [f"upsample.{3*i}" for i in range(n_down)], "output.1")
+        i0, ia, ib = (1, 1, 5) if reflect else (0, 0, 3)
+        return (f"initial.{i0}", [f"downsample.{3*i}" for i in range(n_down)],
+                [(f"res_blocks.{b}.conv_block.{ia}", f"res_blocks.{b}.conv_block.{ib}") for b in range(n_blocks)],
+                [f"upsample.{3*i}" for i in range(n_down)], f"output.{i0}")
     assert style == "basic" and n_down == 2
     base = 10
     ups = base + n_blocks
@@ -70,10 +72,15 @@ class _Net:
 class GeneratorNet(_Net):
     """9-block ResNet generator of both trainers (CUT: biased convs; Basic_GAN: bias-free but the last)."""
 
-    def __init__(self, ctx, params, grads, style="cut", n_blocks=9, ngf=64, in_c=3, out_c=3, need_input_grad=True):
+    def __init__(self, ctx, params, grads, style="cut", n_blocks=9, ngf=64, in_c=3, out_c=3, need_input_grad=True, reflect=True,
+                 block_act=ACT_RELU):
+        """reflect: `padding_type` 'reflect' (the configs' value) or 'zero'; block_act: the residual blocks' activation (ReLU in the
+        configs, LeakyReLU(0.2) for activation='leaky_relu', generator_resnet_attn.py:60-66)."""
         super().__init__(ctx, params, grads)
         self.style, self.n_blocks, self.ngf, self.in_c, self.out_c = style, n_blocks, ngf, in_c, out_c
-        k_init, k_down, k_blk, k_up, k_out = generator_keys(style, n_blocks)
+        self.reflect, self.block_act = reflect, block_act
+        self.pad_mode = HALO_REFLECT if reflect else HALO_ZERO
+        k_init, k_down, k_blk, k_up, k_out = generator_keys(style, n_blocks, reflect=reflect)
         self.c_init = self._conv(k_init, 7, 1, 3, need_dgrad=need_input_grad)
         self.c_down = [self._conv(k, 3, 2, 1) for k in k_down]
         self.c_blk = [(self._conv(a, 3, 1, 1), self._conv(b, 3, 1, 1)) for a, b in k_blk]
@@ -124,7 +131,7 @@ class GPass:
     def halo_mode(self, i: int) -> int:
         nb = self.net.n_blocks
         if i == 2 or (3 <= i < 3 + nb - 1) or i == 4 + nb:
-            return HALO_REFLECT
+            return self.net.pad_mode
         return HALO_ZERO
 
     # ------------------------------------------------------------------ forward
@@ -133,9 +140,9 @@ class GPass:
         net, ops, nb = self.net, self.net.ctx.ops, self.net.n_blocks
         prog = Program("G.fwd")
         if isinstance(src, View):
-            prog.add(ops.view_copy(src, self.x0, HALO_REFLECT))
+            prog.add(ops.view_copy(src, self.x0, net.pad_mode))
         else:
-            prog.add(ops.nchw_to_view(src, net.in_c, self.x0, HALO_REFLECT))
+            prog.add(ops.nchw_to_view(src, net.in_c, self.x0, net.pad_mode))
 
         def norm(i, raw, stats, act, residual=None, out=None, conv=None):
             out = self.acts[i] if out is None else out
@@ -143,7 +150,7 @@ class GPass:
                 prog.add(ops.in_stats_from_parts(net.in_ws(self.B, raw.C), conv.stats_parts, self.B, raw.C, raw.H * raw.W, IN_EPS, stats))
             else:
                 prog.add(ops.in_stats(raw, IN_EPS, stats, net.in_ws(self.B, raw.C)))
-            prog.add(ops.in_apply(raw, stats, act, residual, out, self.halo_mode(i) if out is self.acts[i] else HALO_REFLECT))
+            prog.add(ops.in_apply(raw, stats, act, residual, out, self.halo_mode(i) if out is self.acts[i] else net.pad_mode))
 
         prog.add(net.c_init.fwd(self.x0, self.raw[0]))
         norm(0, self.raw[0], self.stats[0], ACT_RELU)
@@ -160,7 +167,7 @@ class GPass:
             ra, rb = self.raw[i]
             sa, sb = self.stats[i]
             prog.add(ca.fwd(self.acts[i - 1], ra, stats_ws=net.in_ws(self.B, ra.C)))
-            norm(i, ra, sa, ACT_RELU, out=self.mid[k], conv=ca)
+            norm(i, ra, sa, net.block_act, out=self.mid[k], conv=ca)
             prog.add(cb.fwd(self.mid[k], rb, stats_ws=net.in_ws(self.B, rb.C)))
             norm(i, rb, sb, ACT_NONE, residual=self.acts[i - 1], conv=cb)
         for j in range(2):
@@ -182,6 +189,7 @@ class GPass:
         is consumed (PatchNCE).  Weight gradients are written (accumulate=False) or added into net.grads."""
         net, ctx, ops, nb, B = self.net, self.net.ctx, self.net.ctx.ops, self.net.n_blocks, self.B
         hooks = hooks or {}
+        rf = net.reflect      # reflection padding: input gradients are produced on the padded domain and folded by their consumer
         prog = Program("G.bwd")
         H, W, g = self.H, self.W, net.ngf
         acc = accumulate
@@ -241,8 +249,8 @@ class GPass:
             prog.add(ops.act_bwd(self.img, ACT_TANH, g_img, g_img_fold, g_img2, dyo))
             wgrad_side(net.c_out, self.acts[-1], dyo, True)
             g_cur = net.gbuf("g_h4", B, H, W, g, 3)
-            prog.add(net.c_out.dgrad(dyo, g_cur, padded_domain=True))
-            g_fold = True
+            prog.add(net.c_out.dgrad(dyo, g_cur, padded_domain=rf))
+            g_fold = rf
         else:
             a = self.acts[i]
             g_cur = net.gbuf(f"g_act{a.H}x{a.C}", B, a.H, a.W, a.C, 0)
@@ -272,15 +280,15 @@ class GPass:
             inbwd(rb, sb, ACT_NONE, g_cur, False, dyb, cb)
             wgrad_side(cb, self.mid[k], dyb, False)
             g_mid = net.gbuf("g_blk_p", B, h4, w4, c4, 1)
-            prog.add(cb.dgrad(dyb, g_mid, padded_domain=True))
+            prog.add(cb.dgrad(dyb, g_mid, padded_domain=rf))
             dya = net.gbuf(f"dy_blk_a{k % 2}", B, h4, w4, c4, 2)
             before_write(dya)
-            inbwd(ra, sa, ACT_RELU, g_mid, True, dya, ca)
+            inbwd(ra, sa, net.block_act, g_mid, rf, dya, ca)
             wgrad_side(ca, self.acts[i - 1], dya, False)
             g_in_p = net.gbuf("g_blk_p", B, h4, w4, c4, 1)
-            prog.add(ca.dgrad(dya, g_in_p, padded_domain=True))
+            prog.add(ca.dgrad(dya, g_in_p, padded_domain=rf))
             g_next = net.gbuf(f"g_res{k % 2}", B, h4, w4, c4, 0)
-            prog.add(ops.fold_add(g_cur, g_in_p, True, g_next))
+            prog.add(ops.fold_add(g_cur, g_in_p, rf, g_next))
             g_cur = g_next
             i -= 1
         # ---- downsampling layers
@@ -299,8 +307,9 @@ class GPass:
         wgrad_side(net.c_init, self.x0, dy0, False)
         self.g_input = None
         if need_input_grad:
-            self.g_input = net.gbuf("g_x0", B, H, W, self.x0.C, 3)   # padded domain: consumer folds
-            prog.add(net.c_init.dgrad(dy0, self.g_input, padded_domain=True))
+            self.g_input = net.gbuf("g_x0", B, H, W, self.x0.C, 3)   # reflect: padded domain, the consumer folds (g_input_fold)
+            prog.add(net.c_init.dgrad(dy0, self.g_input, padded_domain=rf))
+        self.g_input_fold = rf
         if bias_items:
             prog.add(ops.bias_finalize_batch(bias_items))
         join = ops.new_event()       # everything after this program (next pass, all-reduce, optimiser) sees complete gradients

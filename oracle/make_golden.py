@@ -289,6 +289,28 @@ def gen_optional(tc):
     out["step_sn2.u_after"] = D.state_dict()["discriminators.1.model.6.weight_u"].clone()
     torch.set_num_threads(8)
 
+    # generator variants the reference's constructor offers beside the configs' (reflect, relu): zero padding (no pad modules, so
+    # other state_dict indices) and LeakyReLU residual blocks (generator_resnet_attn.py:24-66,110-162)
+    from GAN_Variant1.models.generator_resnet_attn import ResNetGenerator
+    xg = x[:, :, :32, :32].contiguous()
+    for tag, pad, act in (("gz", "zero", "leaky_relu"), ("grl", "reflect", "leaky_relu")):
+        set_seed(11)
+        Gv = ResNetGenerator(3, 3, ngf=8, n_blocks=2, padding_type=pad, activation=act)
+        for k, v in Gv.state_dict().items():       # the test rebuilds the weights from the same seed: key order and a checksum pin the initialisation
+            out[f"{tag}.init.{k}"] = torch.cat([v.reshape(-1)[:4].double(), v.double().sum().reshape(1)])
+        xr = xg.clone().requires_grad_(True)
+        yv = Gv(xr)
+        feats = Gv.get_feature_layers(xr, [0, 2, 4])
+        wv = torch.randn(yv.shape, generator=g)
+        loss = (yv * wv).sum() + sum((f * f).mean() for f in feats)
+        names = [k for k, _ in Gv.named_parameters()]
+        grads = torch.autograd.grad(loss, [xr] + [p_ for _, p_ in Gv.named_parameters()])
+        out[f"{tag}.w"], out[f"{tag}.y"], out[f"{tag}.loss"], out[f"{tag}.gx"] = wv, yv.detach(), loss.detach(), grads[0]
+        for i, f in enumerate(feats):
+            out[f"{tag}.feat{i}"] = f.detach().clone()
+        for k, gr in zip(names, grads[1:]):
+            out[f"{tag}.gw.{k}"] = gr
+
     # Basic_GAN: spectral norm on the three bias-free middle convolutions only (Basic_GAN/src/models.py:67-69, 87-101)
     from src.losses import GANLoss
     from src.models import NLayerDiscriminator

@@ -199,6 +199,46 @@ def optional_cases(device, tol, tags=("ms3", "sn2")):
         D.train()
 
 
+def generator_variant_cases(device, tol, tags=("gz", "grl")):
+    """ResNetGenerator with padding_type='zero' (no pad modules: other state_dict indices, zero halos, no gradient folding) and / or
+    activation='leaky_relu' in the residual blocks, against vectors the reference produced (cut_optional.npz: gz = zero + leaky_relu,
+    grl = reflect + leaky_relu): initialisation from the same seed, output, feature maps, input and parameter gradients."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cut_optional.npz"))
+    T = lambda k: torch.from_numpy(np.asarray(g[k])).to(device)
+    for tag in tags:
+        pad, act = ("zero", "leaky_relu") if tag == "gz" else ("reflect", "leaky_relu")
+        C.set_seed(11)
+        G = C.ResNetGenerator(3, 3, ngf=8, n_blocks=2, padding_type=pad, activation=act)
+        keys = [k[len(tag) + 6:] for k in g.files if k.startswith(f"{tag}.init.")]
+        assert list(G.state_dict()) == keys, (list(G.state_dict())[:4], keys[:4])
+        for k, v in G.state_dict().items():
+            want = g[f"{tag}.init.{k}"]
+            np.testing.assert_allclose(np.concatenate([v.reshape(-1)[:4].double().numpy(), [float(v.double().sum())]]), want, rtol=1e-6, atol=1e-7, err_msg=k)
+        G = G.to(device)
+        x = T("x")[:, :, :32, :32].contiguous()
+        xr = x.clone().requires_grad_(True)
+        y = G(xr)
+        feats = G.get_feature_layers(xr, [0, 2, 4])
+        _close(y, T(f"{tag}.y"), tol, f"{tag} G(x)")
+        for i, f in enumerate(feats):
+            _close(f, T(f"{tag}.feat{i}"), tol, f"{tag} feature {i}")
+        loss = (y * T(f"{tag}.w")).sum() + sum((f * f).mean() for f in feats)
+        _close(loss, T(f"{tag}.loss"), tol, f"{tag} loss")
+        names = [k for k, _ in G.named_parameters()]
+        grads = torch.autograd.grad(loss, [xr] + [p for _, p in G.named_parameters()])
+        _close(grads[0], T(f"{tag}.gx"), tol * 5, f"{tag} dL/dx")
+        for k, gr in zip(names, grads[1:]):
+            if not k.endswith(".bias") or k.startswith("output"):      # biases in front of a non-affine norm: rounding noise on both sides
+                _close(gr, T(f"{tag}.gw.{k}"), tol * 5, f"{tag} grad {k}")
+
+
+@pytest.mark.parametrize("tag", ["gz", "grl"])
+def test_generator_variants_on_emulator(monkeypatch, tag):
+    monkeypatch.setattr(AG, "_OPS_FACTORY", lambda device: EmuOps())
+    generator_variant_cases(torch.device("cpu"), 2e-4, tags=(tag,))
+
+
 @pytest.mark.parametrize("tag", ["ms3", "sn2", "bsn"])
 def test_optional_discriminators_on_emulator(monkeypatch, tag):
     monkeypatch.setattr(AG, "_OPS_FACTORY", lambda device: EmuOps())

@@ -332,6 +332,13 @@ def test_optional_discriminators_hip(monkeypatch, tag):
     optional_cases(torch.device(DEV), 5e-4, tags=(tag,))
 
 
+@pytest.mark.parametrize("tag", ["gz", "grl"])
+def test_generator_variants_hip(tag):
+    """padding_type='zero' / activation='leaky_relu' generators on the HIP kernels vs vectors produced by the reference."""
+    from tests.test_autograd_bridge import generator_variant_cases
+    generator_variant_cases(torch.device(DEV), 5e-4, tags=(tag,))
+
+
 def test_inference_graph_replay_equals_eager():
     """Forward-only passes of a module with use_graph=True are captured once per input shape and replayed as one hipGraph launch:
     same bits as the eager launches, also after the weights changed (the graph reads the refreshed operand copies)."""
