@@ -169,6 +169,9 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                       # GAN_FORCE_DIST without a launcher: a one-rank group
+            for k, v in (("MASTER_PORT", "29531"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+                os.environ.setdefault(k, v)
         # RCCL prints its banner (host name, library path) on STDOUT when the communicator is created; the contract is ONE JSON
         # line on stdout, so file descriptor 1 points at stderr until the communicator exists
         sys.stdout.flush()
@@ -248,6 +251,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
+
         dist.destroy_process_group()
 
 
