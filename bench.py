@@ -165,6 +165,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
+    # the trainer's compute streams are created and used once BEFORE the process group exists (HipOps.bind_queues)
+    from gan_variant_research_amd.runtime import HipOps
+    ops = HipOps(dev)
+    if not os.environ.get("GAN_NO_BIND_QUEUES"):
+        ops.bind_queues()
     force_dist = bool(int(os.environ.get("GAN_FORCE_DIST", "0")))   # exercise the RCCL path even with one rank
     if world > 1 or force_dist:
         import torch.distributed as dist
@@ -192,8 +197,8 @@ def main():
     cfg = default_config()
     C.set_seed(42)                                       # identical replicas on every rank
     gen, disc = C.build_models(cfg, dev)
-    tr = C.CutTrainer(gen, disc, cfg, args.batch, args.size, device=dev, amp=not args.fp32, world_size=world, process_group=pg)
-    if force_dist:
+    tr = C.CutTrainer(gen, disc, cfg, args.batch, args.size, device=dev, amp=not args.fp32, ops=ops, world_size=world, process_group=pg)
+    if force_dist and not os.environ.get("GAN_FORCE_DIST_NOAR"):
         tr.force_allreduce = True
     g = torch.Generator().manual_seed(1234 + rank)
     photos = (torch.rand(args.batch, 3, args.size, args.size, generator=g) * 2 - 1).to(dev)

@@ -11,6 +11,7 @@ arithmetic runs in libmi355x_gan.so through CutTrainer, which owns the buffers a
 from __future__ import annotations
 
 import math
+import os
 import random
 from typing import Dict, List, Optional, Sequence
 
@@ -627,11 +628,17 @@ class CutTrainer:
         import torch.distributed as dist
         if self.device.type != "cuda":
             return dist.all_reduce(opt.flat_g, group=self.pg, async_op=True), None
-        if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(device=self.device)
         cur = opt.ctx.ops._ts()                                  # the stream the gradients were produced on
-        self._comm_stream.wait_stream(cur)                       # the gradients are complete
-        with torch.cuda.stream(self._comm_stream):
+        if os.environ.get("GAN_COMM_STREAM"):                    # a communication stream of our own in front of RCCL's (not needed: see below)
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=self.device)
+            self._comm_stream.wait_stream(cur)
+            with torch.cuda.stream(self._comm_stream):
+                work = dist.all_reduce(opt.flat_g, group=self.pg, async_op=True)
+            return work, cur
+        # RCCL runs the collective on its own internal stream, ordered after everything queued on the stream that is current at the
+        # call: issuing it under the producing stream needs no extra stream (four compute/communication streams = four hardware queues)
+        with torch.cuda.stream(cur):
             work = dist.all_reduce(opt.flat_g, group=self.pg, async_op=True)
         return work, cur
 
@@ -644,7 +651,8 @@ class CutTrainer:
             return
         with torch.cuda.stream(cur):                             # the stream that produced the gradients (and will consume the
             work.wait()                                          # reduced ones) waits for the collective; the host does not
-        cur.wait_stream(self._comm_stream)
+        if self._comm_stream is not None:
+            cur.wait_stream(self._comm_stream)
 
     _comm_stream = None
 

@@ -427,7 +427,10 @@ class DPass:
         prog = Program("D.bwd")
         dy = g_logits
         self.g_input = None
-        side = ops.side() if (wgrad and keep is None) else None   # weight gradients on the second stream (see GPass.bwd_program)
+        # The discriminator's weight gradients stay on its own stream: they are 2 % of the step, and a fourth compute stream would
+        # share a hardware queue with another one as soon as RCCL adds its stream (HIP multiplexes streams onto four queues;
+        # measured: the discriminator's stream landed on the main stream's queue and the step lost 1.1 ms)
+        side = ops.side() if (wgrad and keep is None and os.environ.get("GAN_D_SIDE")) else None
         for li in range(net.nconv - 1, -1, -1):
             conv = net.convs[li]
             xin = self.acts[li - 1] if li > 0 else self.x

@@ -165,6 +165,7 @@ class HipOps:
         self.torch_stream = torch_stream   # the torch.cuda.Stream behind `stream` (needed for event record / wait)
         self._keep = []       # ctypes structs referenced by prebuilt calls
         self._side = None
+        self._fork = None
 
     # ---- a second HIP stream: independent MFMA-bound launches (weight gradients) run there while the HBM-bound chain
     #      (InstanceNorm backward, reflection folds) continues on the main stream; ordering by events recorded in the programs
@@ -180,8 +181,21 @@ class HipOps:
         """A new op layer on its own (non-blocking) HIP stream of the same device (GAN_SINGLE_STREAM: this one)."""
         if os.environ.get("GAN_SINGLE_STREAM"):
             return self
-        ts = torch.cuda.Stream(device=self.device)
-        return HipOps(self.device, stream=ts.cuda_stream, torch_stream=ts)
+        if self._fork is None:
+            ts = torch.cuda.Stream(device=self.device)
+            self._fork = HipOps(self.device, stream=ts.cuda_stream, torch_stream=ts)
+        return self._fork
+
+    def bind_queues(self):
+        """Creates this op layer's streams (discriminator stream, weight-gradient side stream) and runs one trivial kernel on each.
+        HIP binds a stream to one of its few hardware queues at first use; doing that before anything else creates streams (RCCL does
+        when the process group is set up) keeps the three compute streams on three different queues."""
+        if os.environ.get("GAN_SINGLE_STREAM") or self.device.type != "cuda":
+            return
+        for h in (self, self.fork(), self.side()):
+            with torch.cuda.stream(h._ts()):
+                torch.zeros(64, device=self.device).add_(1.0)
+        torch.cuda.synchronize(self.device)
 
     def _ts(self):
         return self.torch_stream if self.torch_stream is not None else torch.cuda.current_stream(self.device)
