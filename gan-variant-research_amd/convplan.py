@@ -208,7 +208,7 @@ class ConvLayer:
             call = pk.finalize(ConvCall(x.B, ho, wo, pk.cred, pk.ntaps, pk.nw, min(pk.nw, y.C), x, x.halo - p, x.halo - p, s, s,
                                         pk.tapoff(x.Wp), None, self.bias_k if use_bias else None, y, y.halo, y.halo, 1, 1, act, mask,
                                         mask.halo if mask else 0, mask.halo if mask else 0, pk.max_tapoff(x.Wp)))
-            if stats_ws is not None and call.w_frag and call.Nst == y.C and not os.environ.get("GAN_NO_FUSED_STATS"):
+            if stats_ws is not None and (call.w_frag or call.win7 is not None) and call.Nst == y.C and not os.environ.get("GAN_NO_FUSED_STATS"):
                 n = ops.conv_stats_parts(call)
                 if 0 < n and x.B * n * y.C * 2 <= stats_ws.numel():
                     call.stats, self.stats_parts = stats_ws, n

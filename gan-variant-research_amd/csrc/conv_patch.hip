@@ -494,7 +494,9 @@ extern "C" int gan_conv_patch_ok(const gan_conv_desc* d) {
 }
 
 // InstanceNorm partials per image the range-patch kernel writes to d->stats ([B][parts][out_C][2]); 0: this descriptor cannot fuse them
+int gan_conv_win7_stats_parts(const gan_conv_desc* d);
 extern "C" int gan_conv_stats_parts(const gan_conv_desc* d) {
+  if (d && d->w_layout == 2) return gan_conv_win7_stats_parts(d);
   if (!gan_conv_patch_ok(d) || d->act != GAN_ACT_NONE || d->mask || d->out_sy != 1 || d->out_sx != 1) return 0;
   const int BM = patch_tile_rows(d);
   return (d->Ho * d->Wo + BM - 1) / BM;

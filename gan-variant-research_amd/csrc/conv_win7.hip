@@ -20,6 +20,7 @@ struct Win7Args {
   int in_Hp, in_Wp, in_y0, in_x0, ty0, tx0;      // first tap of output (0,0) reads padded pixel (in_y0 + ty0, in_x0 + tx0)
   int out_Hp, out_Wp, out_y0, out_x0;
   int act;
+  float* stats;                                  // 3 -> 64 kernel only: InstanceNorm partials [B][tiles per image][64][2], or null
 };
 
 __global__ __launch_bounds__(256, 2) void conv_win7_kernel(Win7Args a) {
@@ -130,6 +131,18 @@ __global__ __launch_bounds__(256, 2) void conv_win7_kernel(Win7Args a) {
     }
   }
 }
+// sum over the 16 lanes of a DPP row (conv_patch.hip: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror)
+__device__ __forceinline__ float row16_sum_w7(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});
+  v += dpp(v, std::integral_constant<int, 0x4E>{});
+  v += dpp(v, std::integral_constant<int, 0x141>{});
+  v += dpp(v, std::integral_constant<int, 0x140>{});
+  return v;
+}
+
 // ---- the mirror case, 3 (padded 8) -> 64 channels: the generator's first convolution (generator_resnet_attn.py:110-116) and the input
 // gradient of its output convolution.  A pixel is one 16-byte chunk, so a K-step of 32 is FOUR taps (lane group g = lane>>4 reads tap
 // 4*ks+g); 49 taps = 13 K-steps against the generic kernel's 56 tap slots, and the 22x22 window is 7.7 KB.  Wave w owns output channels
@@ -194,12 +207,27 @@ __global__ __launch_bounds__(256, 2) void conv_win7_from3_kernel(Win7Args a, int
   for (int i = 0; i < 4; ++i) bias[i] = a.bias ? a.bias[n0 + i] : 0.f;
   bf16_t* dst = reinterpret_cast<bf16_t*>(a.out) + (((int64_t)b * a.out_Hp + oy0 + a.out_y0) * a.out_Wp + ox0 + x + a.out_x0) * 64 + n0;
   const bool xok = ox0 + x < a.Wo;
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int m = 0; m < TS; ++m) {
+    const float v0 = acc[m].x + bias[0], v1 = acc[m].y + bias[1], v2 = acc[m].z + bias[2], v3 = acc[m].w + bias[3];
     uint2 o;                                                 // no activation on this path (gan_conv_win7_ok)
-    o.x = (uint32_t)f2bf(acc[m].x + bias[0]) | ((uint32_t)f2bf(acc[m].y + bias[1]) << 16);
-    o.y = (uint32_t)f2bf(acc[m].z + bias[2]) | ((uint32_t)f2bf(acc[m].w + bias[3]) << 16);
-    if (xok && oy0 + m < a.Ho) *reinterpret_cast<uint2*>(dst + (int64_t)m * a.out_Wp * 64) = o;
+    o.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+    o.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
+    if (xok && oy0 + m < a.Ho) {
+      *reinterpret_cast<uint2*>(dst + (int64_t)m * a.out_Wp * 64) = o;
+      ssum[0] += v0; ssum[1] += v1; ssum[2] += v2; ssum[3] += v3;          // statistics of the fp32 result, before its rounding
+      ssq[0] += v0 * v0; ssq[1] += v1 * v1; ssq[2] += v2 * v2; ssq[3] += v3 * v3;
+    }
+  }
+  if (a.stats) {      // per (image, tile, channel) sum and sum of squares: lanes of one DPP row hold the 16 pixels of a row for 4 channels
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ssum[i] = row16_sum_w7(ssum[i]); ssq[i] = row16_sum_w7(ssq[i]); }
+    if (x == 0) {
+      float* sp = a.stats + (((int64_t)b * per_img + t2) * 64 + n0) * 2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float2*>(sp + 2 * i) = make_float2(ssum[i], ssq[i]);
+    }
   }
 }
 }  // namespace
@@ -211,11 +239,17 @@ extern "C" int gan_conv_win7_ok(const gan_conv_desc* d) {
   const bool to3 = d->Cin == 64 && d->ntaps == 49 && d->Nw == 16 && d->Nst == 8 && d->out_C == 8;
   const bool from3 = d->Cin == 8 && d->ntaps >= 52 && d->Nw == 64 && d->Nst == 64 && d->out_C == 64;
   if (!to3 && !from3) return 0;
-  if (d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->mask || d->stats) return 0;
+  if (d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->mask || (d->stats && !from3)) return 0;
   if (d->act != GAN_ACT_NONE && !(to3 && d->act == GAN_ACT_TANH)) return 0;
   if (d->max_tapoff != ((d->win_ty0 + 6) * d->in_Wp + d->win_tx0 + 6) * d->Cin) return 0;
   { const char* e = getenv("GAN_NO_WIN7"); if (e && atoi(e)) return 0; }
   return 1;
+}
+
+// tiles per image for which the 3 -> 64 kernel writes InstanceNorm partials to d->stats (0: this descriptor cannot)
+int gan_conv_win7_stats_parts(const gan_conv_desc* d) {
+  if (d->w_layout != 2 || d->Cin != 8 || d->Nst != 64 || d->act != GAN_ACT_NONE) return 0;
+  return ((d->Wo + TS - 1) / TS) * ((d->Ho + TS - 1) / TS);
 }
 
 int gan_conv_win7_launch(const gan_conv_desc* d, hipStream_t s) {
@@ -228,7 +262,7 @@ int gan_conv_win7_launch(const gan_conv_desc* d, hipStream_t s) {
   a.B = d->B; a.Ho = d->Ho; a.Wo = d->Wo; a.tiles_x = (d->Wo + TS - 1) / TS; a.tiles_y = (d->Ho + TS - 1) / TS;
   a.in_Hp = d->in_Hp; a.in_Wp = d->in_Wp; a.in_y0 = d->in_y0; a.in_x0 = d->in_x0; a.ty0 = d->win_ty0; a.tx0 = d->win_tx0;
   a.out_Hp = d->out_Hp; a.out_Wp = d->out_Wp; a.out_y0 = d->out_y0; a.out_x0 = d->out_x0;
-  a.act = d->act;
+  a.act = d->act; a.stats = d->stats;
   const int64_t blocks = (int64_t)d->B * a.tiles_x * a.tiles_y;
   GAN_CHECK(blocks < (1ll << 31), "conv(7x7 window): too many tiles");
   static bool attr_set = false;

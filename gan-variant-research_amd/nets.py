@@ -152,8 +152,8 @@ class GPass:
                 prog.add(ops.in_stats(raw, IN_EPS, stats, net.in_ws(self.B, raw.C)))
             prog.add(ops.in_apply(raw, stats, act, residual, out, self.halo_mode(i) if out is self.acts[i] else net.pad_mode))
 
-        prog.add(net.c_init.fwd(self.x0, self.raw[0]))
-        norm(0, self.raw[0], self.stats[0], ACT_RELU)
+        prog.add(net.c_init.fwd(self.x0, self.raw[0], stats_ws=net.in_ws(self.B, self.raw[0].C)))
+        norm(0, self.raw[0], self.stats[0], ACT_RELU, conv=net.c_init)
         for i in (1, 2):
             if i > self.last:
                 return prog

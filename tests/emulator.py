@@ -112,11 +112,13 @@ class EmuOps:
         to3 = c.Cin == 64 and c.ntaps == 49 and c.Nw == 16 and c.Nst == 8 and c.out.C == 8
         from3 = c.Cin == 8 and c.ntaps >= 52 and c.Nw == 64 and c.Nst == 64 and c.out.C == 64
         return (c.x.dtype == 1 and (to3 or from3) and c.in_sy == 1 and c.in_sx == 1
-                and c.out_sy == 1 and c.out_sx == 1 and c.mask is None and c.stats is None and (c.act == ACT_NONE or (to3 and c.act == ACT_TANH))
+                and c.out_sy == 1 and c.out_sx == 1 and c.mask is None and (c.stats is None or from3) and (c.act == ACT_NONE or (to3 and c.act == ACT_TANH))
                 and c.max_tapoff == ((ty0 + 6) * c.x.Wp + tx0 + 6) * c.Cin)
 
     def conv_stats_parts(self, c):
         """Statement of gan_conv_stats_parts; the emulator reports one part per image."""
+        if getattr(c, "win7", None) is not None:            # 7x7 window path: only the 3 -> 64 kernel writes partials
+            return 1 if (c.Cin == 8 and c.Nst == 64 and c.act == ACT_NONE) else 0
         return 1 if (self.conv_patch_ok(c) and c.act == ACT_NONE and c.mask is None and (c.out_sy, c.out_sx) == (1, 1)) else 0
 
     def in_stats_from_parts(self, parts, nparts, B, Cc, HW, eps, stats):

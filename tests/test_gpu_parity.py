@@ -339,6 +339,33 @@ def test_generator_variants_hip(tag):
     generator_variant_cases(torch.device(DEV), 5e-4, tags=(tag,))
 
 
+@pytest.mark.parametrize("H", [32, 37])
+def test_first_conv_window_kernel_fused_statistics(H):
+    """The 3 -> 64 channel 7x7 window kernel also writes per-tile (sum, sum of squares): with gan_in_stats_from_parts they are the
+    InstanceNorm statistics of its (unrounded) result, ragged tiles included."""
+    from gan_variant_research_amd.convplan import ConvLayer
+    B, Cc = 3, 64
+    ctx = hip_ctx(BF16)
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(B, 3, H, H, generator=g) * 2 - 1).bfloat16().float()
+    w = torch.randn(Cc, 3, 7, 7, generator=g) * 0.08
+    b = torch.randn(Cc, generator=g) * 0.5
+    layer = ConvLayer(ctx, w.to(DEV), b.to(DEV), torch.zeros_like(w).to(DEV), torch.zeros_like(b).to(DEV), 7, 1, 3)
+    xin = cases.to_view(ctx, x, 3, 2)
+    y = ctx.view(B, H, H, Cc, 0)
+    ws = ctx.f32(B * 1024 * Cc * 2)
+    ops = layer.fwd(xin, y, stats_ws=ws)
+    assert layer.stats_parts == (-(-H // 16)) ** 2, layer.stats_parts
+    st = ctx.f32(B * Cc * 2)
+    for o in layer.repack_ops() + ops + [ctx.ops.in_stats_from_parts(ws, layer.stats_parts, B, Cc, H * H, 1e-5, st)]:
+        o()
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (3, 3, 3, 3), mode="reflect"), w.bfloat16().float(), b)
+    sg = st.cpu().view(B, Cc, 2)
+    np.testing.assert_allclose(sg[..., 0].numpy(), ref.mean((2, 3)).numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(sg[..., 1].numpy(), (1.0 / torch.sqrt(ref.var((2, 3), unbiased=False) + 1e-5)).numpy(), rtol=2e-3)
+
+
 def test_inference_graph_replay_equals_eager():
     """Forward-only passes of a module with use_graph=True are captured once per input shape and replayed as one hipGraph launch:
     same bits as the eager launches, also after the weights changed (the graph reads the refreshed operand copies)."""
