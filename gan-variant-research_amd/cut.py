@@ -538,7 +538,7 @@ class CutTrainer:
                 pg.add(ops.view_copy(g_img, g13.batch(0, B), HALO_NONE))
             pg.add(ops.l1_loss(p1.img.batch(B, B), 3, self.monets, 1.0, self._slot("idw"), self._slot("identity"), g13.batch(B, B),
                                ctx.scratch("l1_ws", 1024)))
-            pg.add(p1.bwd_program(g13, accumulate=True))
+            pg.add(p1.bwd_program(g13, accumulate=True, bucket=self._bucket_plan()))
         else:
             pg.add(p1.bwd_program(g_img, g_fold, g_img2, accumulate=True))
             # identity (identity_l1.py:6-22): third pass, gradient scaled by the device-resident identity weight
@@ -644,6 +644,43 @@ class CutTrainer:
             work = dist.all_reduce(opt.flat_g, group=self.pg, async_op=True)
         return work, cur
 
+    # ---- two gradient buckets for the generator: [residual block K .. output] is reduced while the backward of the earlier layers
+    #      still runs (GPass.bwd_program(bucket=...)); the head of the flat gradient follows after the program
+    BUCKET_BLOCK = 2
+
+    def _bucket_plan(self):
+        """(block index, callback) for the merged generator backward, or None (single all-reduce after the backward)."""
+        nb = self.generator.n_blocks
+        if os.environ.get("GAN_NO_BUCKET_AR") or nb <= self.BUCKET_BLOCK or self.device.type != "cuda":
+            return None
+        i = self.opt_G.names.index(f"res_blocks.{self.BUCKET_BLOCK}.conv_block.1.weight")
+        self._bucket_off = int(self.opt_G.offsets[i])
+        return (self.BUCKET_BLOCK, self._bucket_start)
+
+    _bucket_work, _bucket_off = None, 0
+
+    def _bucket_start(self):
+        """Called from inside the backward program: all-reduce of flat_g[off:] ordered after the side stream's position."""
+        if not (self.world_size > 1 or getattr(self, "force_allreduce", False)):
+            return
+        import torch.distributed as dist
+        with torch.cuda.stream(self.ops.side()._ts()):
+            self._bucket_work = dist.all_reduce(self.opt_G.flat_g[self._bucket_off:], group=self.pg, async_op=True)
+
+    def _allreduce_G(self):
+        """The generator's gradient all-reduce: whole block, or the head only when the tail bucket is already in flight."""
+        work = self._bucket_work
+        if work is None:
+            self._allreduce(self.opt_G)
+            return
+        self._bucket_work = None
+        import torch.distributed as dist
+        cur = self.opt_G.ctx.ops._ts()
+        with torch.cuda.stream(cur):
+            head = dist.all_reduce(self.opt_G.flat_g[:self._bucket_off], group=self.pg, async_op=True)
+            work.wait()
+            head.wait()
+
     def _allreduce_finish(self, handle):
         if handle is None:
             return
@@ -718,7 +755,7 @@ class CutTrainer:
         self.prog_g_compute.run()
         if idw > 0 and self.prog_g_identity is not None:
             self.prog_g_identity.run()
-        self._allreduce(self.opt_G)
+        self._allreduce_G()
         self.prog_g_update.run()
         _notify_weights_changed()          # parameters changed through raw pointers: module-level bridges repack on next use
         if sync is False:

@@ -183,7 +183,7 @@ class GPass:
     # ------------------------------------------------------------------ backward
     def bwd_program(self, g_img: Optional[View] = None, g_img_fold: bool = False, g_img2: Optional[View] = None,
                     hooks: Optional[Dict[int, Callable[[View], list]]] = None, accumulate: bool = False,
-                    need_input_grad: bool = False) -> Program:
+                    need_input_grad: bool = False, bucket: Optional[tuple] = None) -> Program:
         """Backward of this pass.  g_img (+ g_img2): gradient wrt the output image (folded over a reflect halo if
         g_img_fold).  hooks[i](g_view) returns ops that add extra gradient into activation i's gradient before it
         is consumed (PatchNCE).  Weight gradients are written (accumulate=False) or added into net.grads."""
@@ -290,6 +290,18 @@ class GPass:
             g_next = net.gbuf(f"g_res{k % 2}", B, h4, w4, c4, 0)
             prog.add(ops.fold_add(g_cur, g_in_p, rf, g_next))
             g_cur = g_next
+            if bucket is not None and k == bucket[0]:
+                # Gradient bucket for data parallelism: every layer from residual block k to the output has its final gradient once
+                # the launches queued so far have run -- weight gradients on the side stream, bias sums on this one.  The callback
+                # (the trainer's) starts the all-reduce of that slice of the flat gradient behind BOTH, so that it overlaps the rest
+                # of this backward; the side stream is only used to carry the two conditions, it does not wait for the collective.
+                if bias_items:
+                    prog.add(ops.bias_finalize_batch(list(bias_items)))
+                    del bias_items[:]
+                ev_b = ops.new_event()
+                prog.add(ops.record(ev_b))
+                prog.add(side.wait(ev_b))
+                prog.add(bucket[1])
             i -= 1
         # ---- downsampling layers
         while i >= 1:

@@ -1,4 +1,6 @@
 """Parity tests proper (MI355X, through the C ABI): every HIP kernel against its CPU statement / the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -364,6 +366,27 @@ def test_first_conv_window_kernel_fused_statistics(H):
     sg = st.cpu().view(B, Cc, 2)
     np.testing.assert_allclose(sg[..., 0].numpy(), ref.mean((2, 3)).numpy(), rtol=2e-3, atol=2e-3)
     np.testing.assert_allclose(sg[..., 1].numpy(), (1.0 / torch.sqrt(ref.var((2, 3), unbiased=False) + 1e-5)).numpy(), rtol=2e-3)
+
+
+def test_rccl_path_with_one_rank_changes_nothing():
+    """bench.py with a one-rank RCCL group (GAN_FORCE_DIST=1: stream binding before the group exists, discriminator all-reduce on its
+    stream, the generator's two gradient buckets with the tail overlapping the backward) must produce the same losses, bit for bit, as
+    the plain run and as the single-all-reduce variant: a collective issued before its gradients are final would show up here only with
+    more ranks, but a mis-sliced bucket, a missing wait or a wrong stream shows up as a different loss or a hang."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in ({}, {"GAN_FORCE_DIST": "1", "MASTER_PORT": "29583"}, {"GAN_FORCE_DIST": "1", "GAN_NO_BUCKET_AR": "1", "MASTER_PORT": "29584"}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "2", "--batch", "4", "--size", "128", "--no-cpu-baseline"], cwd=root, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, lines                      # ONE JSON line on stdout, RCCL's banner included nowhere
+        outs.append(json.loads(lines[0])["last_losses"])
+    assert outs[0] == outs[1] == outs[2], outs
 
 
 def test_inference_graph_replay_equals_eager():
