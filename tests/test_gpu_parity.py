@@ -376,10 +376,18 @@ def test_rccl_path_with_one_rank_changes_nothing():
     import json
     import subprocess
     import sys
+    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def free_port():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            return str(sk.getsockname()[1])
     outs = []
-    for extra in ({}, {"GAN_FORCE_DIST": "1", "MASTER_PORT": "29583"}, {"GAN_FORCE_DIST": "1", "GAN_NO_BUCKET_AR": "1", "MASTER_PORT": "29584"}):
+    for extra in ({}, {"GAN_FORCE_DIST": "1"}, {"GAN_FORCE_DIST": "1", "GAN_NO_BUCKET_AR": "1"}):
         env = dict(os.environ, **extra)
+        if extra:
+            env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port(), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         r = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "2", "--batch", "4", "--size", "128", "--no-cpu-baseline"], cwd=root, env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
