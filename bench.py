@@ -50,13 +50,14 @@ def dominant_kernel_roofline(trainer, iters=10):
     them are replayed back to back `iters` times between two HIP events on the launch stream, so that
       ms_per_launch = elapsed / (iters * launches)  is the figure `rocprofv3 --kernel-trace --stats` reports as the kernel's
       average duration for the same step (profiles/), and
-      achieved = sum of algorithmic FLOPs (2 * B*Ho*Wo * Nst * Cin * ntaps per launch) / elapsed.
+      achieved = sum of algorithmic FLOPs (ConvCall.alg_flops: 2*M*N*K with M the REFERENCE op's output pixels -- an input
+      gradient launched on the reflect-padded 66x66 domain is priced as 64x64) / elapsed.
     fp32 (--fp32): the same over every `conv_igemm_kernel` launch.  The single 3x3 256->256 forward (77.3 GFLOP at B=16) is
     reported beside it as `res_fwd_*`."""
     bf16 = trainer.amp.enabled
     progs = [trainer.prog_gfwd, trainer.prog_d_compute, trainer.prog_d_update, trainer.prog_g_features, trainer.prog_g_adversarial, trainer.prog_g_features_bwd, trainer.prog_g_compute, trainer.prog_g_identity, trainer.prog_g_update]
     calls = [o for p in progs if p is not None for o in p.ops if getattr(o, "conv", None) is not None and (o.conv.w_frag or not bf16)]
-    flops = sum(2.0 * o.conv.B * o.conv.Ho * o.conv.Wo * o.conv.Nst * o.conv.Cin * o.conv.ntaps * o.conv.flop_scale for o in calls)
+    flops = sum(o.conv.alg_flops() for o in calls)      # SURVEY §8d: 2*M*N*K with M the reference op's output pixels
 
     def timed(ops, n):
         """ms per pass over `ops`, between two HIP events on the caller's stream; launches that the programs put on the trainer's
@@ -116,7 +117,7 @@ def pmc_traffic(kernel_prefix):
     return round(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n) if n else None
 
 
-def cpu_baseline(image_size=256, batch=2, steps=2):
+def cpu_baseline(image_size=256, batch=2, steps=8):
     """The oracle (oracle/cut_ref.py, checked against the reference) on the host cores: same step, fp32, B=2."""
     from oracle import cut_ref
     # the GPU box gives one job a share of the host (16 cores per GPU): never oversubscribe it
@@ -142,6 +143,48 @@ def cpu_baseline(image_size=256, batch=2, steps=2):
             "sample": f"{steps} timed steps of the same CUT step at {image_size}x{image_size}, batch {batch}, fp32, after 1 warm-up step"}
 
 
+def launch_ranks(n: int) -> None:
+    """`python bench.py --gpus N` without a launcher: start N fresh processes of this script, one per GPU, with the environment
+    torch.distributed.run would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), relay rank 0's JSON line
+    and fail if any rank fails.  This parent never touches the GPU, and nothing that has initialised the GPU is exec'ed."""
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL's peer mappings need it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        failed = next((p for p in procs if p.poll() not in (None, 0)), None)
+    failed = failed or next((p for p in procs if p.returncode != 0), None)
+    if failed is not None:          # one rank died: the others would wait in a collective, stop exactly the processes started here
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=10)
+    for ln in lines:                # rank 0 prints ONE JSON line; anything else it wrote goes to stderr
+        (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln)
+    sys.stdout.flush()
+    if failed is not None:
+        raise SystemExit(f"[bench] rank {procs.index(failed)} exited with code {failed.returncode}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,15 +196,29 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["cut", "basic"], default="cut",
                     help="cut: BASELINE.json configs[2] (the metric's config); basic: configs[1], Basic_GAN CycleGAN 64x64 batch 256")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="no GPU work: every rank joins a gloo group on the host, rank 0 prints the rank count (tests the --gpus N launcher)")
     args = ap.parse_args()
     if args.workload == "basic":
         return main_basic(args)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)       # plain `python bench.py --gpus N`: this process becomes the launcher (no GPU call before)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
+    if args.launch_check:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "max_rank": int(t.item())}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None

@@ -69,6 +69,7 @@ class _Pack:
         c.w = None
         if self.ctx.ops.conv_patch_ok(c):
             c.w, c.w_frag = self.wf, True
+            c.tile_rows = self.ctx.ops.conv_patch_tile_rows(c)
         else:
             c.w, c.w_frag = self.w, False
             # the 64 -> 3 channel 7x7 layers: the window kernel reads the same row-major weight copy
@@ -275,8 +276,10 @@ class ConvLayer:
                 assert dy.halo >= k - 1 - p
                 gh, gw, oy, iy = dx.H, dx.W, dx.halo, dy.halo - (k - 1) + p
             assert gh == dy.H + k - 1 - (0 if padded_domain else 2 * p), (gh, dy.H, k, p)
-            return [ops.conv_igemm(pk.finalize(ConvCall(dy.B, gh, gw, pk.cred, pk.ntaps, pk.nw, min(pk.nw, dx.C), dy, iy, iy, 1, 1, pk.tapoff(dy.Wp), None,
-                                            None, dx, oy, oy, 1, 1, ACT_NONE, mask, mask.halo if mask else 0, mask.halo if mask else 0, pk.max_tapoff(dy.Wp))))]
+            call = pk.finalize(ConvCall(dy.B, gh, gw, pk.cred, pk.ntaps, pk.nw, min(pk.nw, dx.C), dy, iy, iy, 1, 1, pk.tapoff(dy.Wp), None,
+                                        None, dx, oy, oy, 1, 1, ACT_NONE, mask, mask.halo if mask else 0, mask.halo if mask else 0, pk.max_tapoff(dy.Wp)))
+            call.alg_pixels = dy.H * dy.W      # the reference op's M is the forward output (dy) pixel count, not the (padded) input domain
+            return [ops.conv_igemm(call)]
         assert not padded_domain and (dx.H, dx.W) == (2 * dy.H, 2 * dy.W)
         return self._phased(self.dgrad_packs, dy, dx, ACT_NONE, None, mask)
 

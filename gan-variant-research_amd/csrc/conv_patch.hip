@@ -24,6 +24,7 @@
 //    emits the InstanceNorm statistics of its tile (gan_conv_desc.stats) with DPP row reductions.
 #include <stdlib.h>
 #include <type_traits>
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -459,12 +460,14 @@ static int patch_span(const gan_conv_desc* d, int BM) {
   return (rows - 1) * d->in_sx + wraps * (jump > 0 ? jump : 0) + maxtap + 1;
 }
 
-// tile height: the one that needs the fewest CU-rounds x rows (GAN_PATCH_BM forces one; tuning aid, read per call so a test can toggle it)
-static int patch_tile_rows(const gan_conv_desc* d) {
+// tile height: the planner's choice if the descriptor carries one, otherwise the one that needs the fewest CU-rounds x rows
+// (GAN_PATCH_BM forces one; a tuning aid that only the planning call gan_conv_patch_tile_rows reads)
+static int patch_tile_rows(const gan_conv_desc* d, bool planning = false) {
   const int M_img = d->Ho * d->Wo, ncu = 256;
   int BM = 0, forced = 0;
   int64_t best = 0;
-  { const char* e = getenv("GAN_PATCH_BM"); forced = e ? atoi(e) : 0; }
+  if (!planning && (d->tile_rows == 256 || d->tile_rows == 288) && patch_span(d, d->tile_rows) <= RMAX) return d->tile_rows;
+  if (planning) { const char* e = getenv("GAN_PATCH_BM"); forced = e ? atoi(e) : 0; }
   for (int cand : {256, 288}) {
     if (patch_span(d, cand) > RMAX || (forced && forced != cand && patch_span(d, forced) <= RMAX)) continue;
     const int64_t tiles = (int64_t)d->B * ((M_img + cand - 1) / cand) * ((d->Nst + BN - 1) / BN);
@@ -493,6 +496,10 @@ extern "C" int gan_conv_patch_ok(const gan_conv_desc* d) {
   return 4 * M_img >= 3 * rows ? 1 : 0;
 }
 
+extern "C" int gan_conv_patch_tile_rows(const gan_conv_desc* d) {
+  return gan_conv_patch_ok(d) ? patch_tile_rows(d, true) : 0;
+}
+
 // InstanceNorm partials per image the range-patch kernel writes to d->stats ([B][parts][out_C][2]); 0: this descriptor cannot fuse them
 int gan_conv_win7_stats_parts(const gan_conv_desc* d);
 extern "C" int gan_conv_stats_parts(const gan_conv_desc* d) {
@@ -519,21 +526,27 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   a.Nst = d->Nst; a.act = d->act; a.stats = d->stats;
   if (d->stats && (d->act != GAN_ACT_NONE || d->mask)) return gan_set_error(-1, "conv: fused statistics need act = none and no mask");
   a.mask_Hp = d->mask_Hp; a.mask_Wp = d->mask_Wp; a.mask_y0 = d->mask_y0; a.mask_x0 = d->mask_x0;
-  { const char* e = getenv("GAN_PATCH_STAMPS"); a.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
+  // diagnostic environment (stamp buffer, static-schedule switch): read once per process, not per launch
+  static unsigned long long* const stamps_env = [] { const char* e = getenv("GAN_PATCH_STAMPS"); return e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }();
+  static const bool static_off = [] { const char* e = getenv("GAN_PATCH_STATIC"); return e && !atoi(e); }();
+  a.stamps = stamps_env;
   const int grid = a.tiles < ncu ? a.tiles : ncu;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the dynamic-LDS limit is a per-device function attribute: one bit per device, set on that device's first launch
+  static std::atomic<uint64_t> attr_devs{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return gan_set_error(-2, "conv_patch: hipGetDevice failed");
+  const uint64_t dev_bit = 1ull << (dev & 63);
+  if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
     if (hipFuncSetAttribute((const void*)conv_patch_kernel<256, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)conv_patch_kernel<288, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)conv_patch_kernel<256, 2, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return gan_set_error(-2, "conv_patch: cannot raise the dynamic LDS limit to %d bytes", LDS_BYTES);
-    attr_set = true;
+    attr_devs.fetch_or(dev_bit, std::memory_order_release);
   }
   // The static 3x3 schedule, 256-row tile only.  Measured (s_memtime): 15.5 k -> 13.0 k cycles per slab, but the denser issue
   // stream clocks lower (2.04 -> 1.88 GHz), so the forward gains 3 % wall (69.5 -> 67.2 us = 1.15 PFLOP/s); on the 288-row tile,
   // whose 9 fragment addresses per tap do not fit in registers, it lost 9 % and is not instantiated.
-  bool st9 = BM == 256 && d->ntaps == 9 && a.nchunk % 2 == 0;
-  { const char* e = getenv("GAN_PATCH_STATIC"); if (e && !atoi(e)) st9 = false; }
+  const bool st9 = BM == 256 && d->ntaps == 9 && a.nchunk % 2 == 0 && !static_off;
   if (BM == 256) {
     if (st9) hipLaunchKernelGGL((conv_patch_kernel<256, 2, 9>), dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<256, 2, 0>), dim3(grid), dim3(NTHR), LDS_BYTES, s, a);

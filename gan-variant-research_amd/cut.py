@@ -651,7 +651,7 @@ class CutTrainer:
     def _bucket_plan(self):
         """(block index, callback) for the merged generator backward, or None (single all-reduce after the backward)."""
         nb = self.generator.n_blocks
-        if os.environ.get("GAN_NO_BUCKET_AR") or nb <= self.BUCKET_BLOCK or self.device.type != "cuda":
+        if os.environ.get("GAN_NO_BUCKET_AR") or nb <= self.BUCKET_BLOCK:
             return None
         i = self.opt_G.names.index(f"res_blocks.{self.BUCKET_BLOCK}.conv_block.1.weight")
         self._bucket_off = int(self.opt_G.offsets[i])
@@ -664,6 +664,9 @@ class CutTrainer:
         if not (self.world_size > 1 or getattr(self, "force_allreduce", False)):
             return
         import torch.distributed as dist
+        if self.device.type != "cuda":       # host tensors (gloo): the launches queued before this callback have already run
+            self._bucket_work = dist.all_reduce(self.opt_G.flat_g[self._bucket_off:], group=self.pg, async_op=True)
+            return
         with torch.cuda.stream(self.ops.side()._ts()):
             self._bucket_work = dist.all_reduce(self.opt_G.flat_g[self._bucket_off:], group=self.pg, async_op=True)
 
@@ -675,6 +678,11 @@ class CutTrainer:
             return
         self._bucket_work = None
         import torch.distributed as dist
+        if self.device.type != "cuda":
+            head = dist.all_reduce(self.opt_G.flat_g[:self._bucket_off], group=self.pg, async_op=True)
+            work.wait()
+            head.wait()
+            return
         cur = self.opt_G.ctx.ops._ts()
         with torch.cuda.stream(cur):
             head = dist.all_reduce(self.opt_G.flat_g[:self._bucket_off], group=self.pg, async_op=True)
@@ -722,6 +730,14 @@ class CutTrainer:
         """One iteration; returns the reference's loss dict (train_cutpp.py:315-323).  sync=True reads the losses back before
         returning (the reference's .item() calls); sync="lag" returns the PREVIOUS step's dict (see flush_losses); sync=False skips
         the read-back and the NaN check and returns None."""
+        if self.device.type != "cuda":
+            return self._train_step(step, photos, monets, rnd, sync)
+        # the programs launch on the stream the op layer was bound to at construction; the torch-side copies, fills and events of a
+        # step must be queued on that same stream whatever the caller has made current
+        with torch.cuda.stream(self.ops._ts()):
+            return self._train_step(step, photos, monets, rnd, sync)
+
+    def _train_step(self, step, photos, monets, rnd, sync):
         cfg = self.config
         lw = cfg["loss_weights"]
         idw = identity_weight_at(step, cfg)

@@ -94,9 +94,17 @@ class ConvCall:
     mask_x0: int = 0
     max_tapoff: int = 0
     w_frag: bool = False      # w is the fragment-major copy (range-patch kernel)
+    tile_rows: int = 0        # range-patch kernel: pixels per tile, fixed at planning time (HipOps.conv_patch_tile_rows)
     stats: Optional[torch.Tensor] = None   # InstanceNorm partials written by the epilogue (see HipOps.conv_stats_parts)
     win7: Optional[tuple] = None           # (ty0, tx0): run by the 7x7 window kernel, taps row-major from that position (w_layout 2)
     flop_scale: float = 1.0                # algorithmic / launched FLOPs (paired phases multiply by zero blocks: 0.75); bench.py prices with it
+    alg_pixels: Optional[int] = None       # output pixels per image of the REFERENCE op this launch implements, when they differ from Ho*Wo
+                                           # (stride-1 input gradients run on the input's -- possibly reflect-padded -- domain); SURVEY §8d
+
+    def alg_flops(self) -> float:
+        """Algorithmic FLOPs (2*M*N*K with M the reference op's output pixels), what bench.py and tools/step_ops.py price."""
+        px = self.Ho * self.Wo if self.alg_pixels is None else self.alg_pixels
+        return 2.0 * self.B * px * self.Nst * self.Cin * self.ntaps * self.flop_scale
 
 
 @dataclass
@@ -161,7 +169,12 @@ class HipOps:
     def __init__(self, device: torch.device, stream: Optional[int] = None, torch_stream=None):
         self.lib = _lib.load()
         self.device = device
-        self.stream = stream  # None: torch's current stream at op-construction time
+        if stream is None and self.device.type == "cuda":
+            # bind to the stream that is current NOW: launches (raw handle baked into the prebuilt calls) and the torch-side events,
+            # copies and collectives (_ts) must always meet on one stream, whatever is current when a program is replayed
+            torch_stream = torch.cuda.current_stream(self.device)
+            stream = torch_stream.cuda_stream
+        self.stream = stream
         self.torch_stream = torch_stream   # the torch.cuda.Stream behind `stream` (needed for event record / wait)
         self._keep = []       # ctypes structs referenced by prebuilt calls
         self._side = None
@@ -262,6 +275,7 @@ class HipOps:
         d.stats = c.stats.data_ptr() if c.stats is not None else None
         d.max_tapoff = c.max_tapoff
         d.w_layout = 1 if c.w_frag else 0
+        d.tile_rows = c.tile_rows
         if c.win7 is not None:
             assert not c.w_frag
             d.w_layout, d.win_ty0, d.win_tx0 = 2, c.win7[0], c.win7[1]
@@ -271,6 +285,10 @@ class HipOps:
     def conv_patch_ok(self, c: ConvCall) -> bool:
         """True if the range-patch kernel takes this call (then `c.w` must be the fragment-major weight copy)."""
         return bool(self.lib.gan_conv_patch_ok(C.byref(self._conv_desc(c))))
+
+    def conv_patch_tile_rows(self, c: ConvCall) -> int:
+        """Pixels per tile the range-patch kernel uses for this call (0: not eligible); planned once, carried in the descriptor."""
+        return int(self.lib.gan_conv_patch_tile_rows(C.byref(self._conv_desc(c))))
 
     def conv_win7_ok(self, c: ConvCall, ty0: int, tx0: int) -> bool:
         """True if the 7x7 window kernel takes this call with its 49 row-major taps starting at (ty0, tx0)."""

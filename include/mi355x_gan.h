@@ -65,6 +65,9 @@ typedef struct gan_conv_desc {
                                     for the range-patch kernel (the descriptor must satisfy gan_conv_patch_ok); 2: w as for 0, run
                                     by the 7x7 window kernel (the descriptor must satisfy gan_conv_win7_ok) */
   int32_t win_ty0, win_tx0;      /* w_layout 2: tapoff[t] = ((win_ty0 + t/7) * in_Wp + win_tx0 + t%7) * Cin, t = 0..48 */
+  int32_t tile_rows;             /* w_layout 1: output pixels per tile (256 or 288), fixed by the planner with gan_conv_patch_tile_rows so
+                                    that the launch and the partial count of `stats` (gan_conv_stats_parts) agree; 0: chosen at launch */
+  int32_t _pad;
 } gan_conv_desc;
 
 /* Weight-gradient GEMM: part[s][n][t][c] = sum over the rows m of split s of
@@ -97,6 +100,9 @@ int gan_conv_igemm(const gan_conv_desc* d, void* stream);
 /* 1 if the descriptor qualifies for the range-patch kernel (bf16, Cin % 64 == 0, Nw % 128 == 0, one tile's pixel span fits
  * the LDS slab); pure host-side predicate used by the planner to choose the weight layout */
 int gan_conv_patch_ok(const gan_conv_desc* d);
+/* pixels per tile the range-patch kernel would choose for this descriptor (256 or 288: the one with the fewest CU-rounds x rows; the
+ * tuning variable GAN_PATCH_BM is read HERE, at planning time, never at launch); 0 if the descriptor does not qualify */
+int gan_conv_patch_tile_rows(const gan_conv_desc* d);
 /* 1 if the descriptor qualifies for a 7x7 window kernel (bf16, stride 1, 49 row-major taps located by win_ty0/win_tx0, act none or
  * tanh, no mask / stats): Cin = 64, Nw = 16, Nst = out_C = 8 (the 64 -> 3 channel layers) or Cin = 8, Nw = Nst = out_C = 64 with the
  * tap list padded to >= 52 (the 3 -> 64 channel layers) */

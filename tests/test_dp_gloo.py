@@ -40,34 +40,79 @@ def _make(B, world=1, pg=None):
     return C.CutTrainer(gen, disc, cfg, B, S, device="cpu", amp=False, ops=EmuOps(), world_size=world, process_group=pg)
 
 
-def _worker(rank, world, port, out):
+def _bucket_op_index(tr):
+    """Position of the tail-bucket callback inside the merged generator backward (GPass.bwd_program(bucket=...))."""
+    idx = [i for i, op in enumerate(tr.prog_g_compute.ops) if getattr(op, "__self__", None) is tr and op.__func__ is C.CutTrainer._bucket_start]
+    assert len(idx) == 1, idx
+    return idx[0]
+
+
+def _worker(rank, world, port, out, early=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     bl = BG // world
+    calls = []
+    orig = C.CutTrainer._bucket_start
+
+    def counted(self):
+        calls.append(int(self._bucket_off))
+        orig(self)
+        assert self._bucket_work is not None       # an asynchronous gloo collective on flat_g[off:] is in flight
+    C.CutTrainer._bucket_start = counted
     tr = _make(bl, world, dist.group.WORLD)
+    i = [k for k, op in enumerate(tr.prog_g_compute.ops) if getattr(op, "__self__", None) is tr and getattr(op, "__func__", None) is counted]
+    assert len(i) == 1 and 0 < tr._bucket_off < tr.opt_G.flat_g.numel()
+    if early:      # the defect the test must catch: the tail bucket reduced before its weight gradients / bias sums are complete
+        ops = tr.prog_g_compute.ops
+        ops.insert(0, ops.pop(i[0]))
     photos, monets = _inputs()
     ref = _make(BG)                      # only used to draw the GLOBAL randomness with the same consumption order
     rnd = _shard(_global_randomness(ref), rank * bl, (rank + 1) * bl)
     losses = tr.train_step(0, photos[rank * bl:(rank + 1) * bl], monets[rank * bl:(rank + 1) * bl], rnd)
+    assert calls == [tr._bucket_off], calls          # the two-bucket path ran (once), not the single all-reduce
     if rank == 0:
         out["g"] = {k: v.clone() for k, v in tr.opt_G.params.items()}
         out["d"] = {k: v.clone() for k, v in tr.opt_D.params.items()}
+        out["flat_g"], out["flat_gd"], out["bucket_off"] = tr.opt_G.flat_g.clone(), tr.opt_D.flat_g.clone(), tr._bucket_off
     out[f"loss{rank}"] = losses
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_rank():
+def _run_two_ranks(early=False):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
-    torch.set_num_threads(4)
-    single = _make(BG)
-    photos, monets = _inputs()
-    ref_losses = single.train_step(0, photos, monets, _global_randomness(single))
+    mp.spawn(_worker, args=(2, port, out, early), nprocs=2, join=True)
+    return out
+
+
+_single = {}
+
+
+def _single_rank():
+    if not _single:
+        torch.set_num_threads(4)
+        tr = _make(BG)
+        photos, monets = _inputs()
+        _single["tr"], _single["losses"] = tr, tr.train_step(0, photos, monets, _global_randomness(tr))
+    return _single["tr"], _single["losses"]
+
+
+def _grad_err(two, one):
+    return float((two / 2 - one).abs().max() / one.abs().max())
+
+
+def test_two_ranks_equal_one_rank():
+    """Runs the overlapped two-bucket generator all-reduce (cut._bucket_plan/_bucket_start/_allreduce_G) with asynchronous gloo
+    collectives: the summed gradient block itself must equal the one-rank gradient (parameters after Adam's sign-like first
+    update would hide a wrong magnitude)."""
+    out = _run_two_ranks()
+    single, ref_losses = _single_rank()
+    assert _grad_err(out["flat_g"], single.opt_G.flat_g) < 2e-4
+    assert _grad_err(out["flat_gd"], single.opt_D.flat_g) < 2e-4
     for k in ("d_loss", "g_adv", "nce", "identity", "r1"):   # batch means: the global value is the mean of the rank values
         avg = 0.5 * (out["loss0"][k] + out["loss1"][k])
         np.testing.assert_allclose(avg, ref_losses[k], rtol=2e-4, atol=2e-5, err_msg=k)
@@ -75,3 +120,13 @@ def test_two_ranks_equal_one_rank():
         for k, v in out[name].items():
             # Adam's first update is +-lr * sign(g): allow one sign flip (2 lr) on near-zero gradients, twice for D (R1 step)
             np.testing.assert_allclose(v.numpy(), opt.params[k].numpy(), rtol=0, atol=4.5e-4 * (2 if name == "d" else 1), err_msg=k)
+
+
+def test_tail_bucket_issued_too_early_is_caught():
+    """The same run with the tail bucket's all-reduce moved to the front of the backward program (before the weight gradients and
+    bias sums of its layers are queued) must NOT reproduce the one-rank gradient: the check above can see a premature collective."""
+    out = _run_two_ranks(early=True)
+    single, _ = _single_rank()
+    off = out["bucket_off"]
+    assert _grad_err(out["flat_g"][:off], single.opt_G.flat_g[:off]) < 2e-4        # the head bucket is still right
+    assert _grad_err(out["flat_g"][off:], single.opt_G.flat_g[off:]) > 1e-2        # the tail is not

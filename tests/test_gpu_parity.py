@@ -397,6 +397,64 @@ def test_rccl_path_with_one_rank_changes_nothing():
     assert outs[0] == outs[1] == outs[2], outs
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (one RCCL rank per GPU)")
+def test_two_gpu_ranks_equal_one_rank(tmp_path):
+    """Two fresh ranks, one per GPU, over RCCL with the overlapped two-bucket generator all-reduce on: the summed gradient blocks and
+    the mean losses of CUT step 0 must equal the one-rank run on the global batch (the assertion of tests/test_dp_gloo.py, on HIP)."""
+    import socket
+    import subprocess
+    import sys
+    from gan_variant_research_amd import cut as C
+    from tests import test_dp_gloo as T
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    out = str(tmp_path / "rank")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "dp_hip_worker.py"), out], cwd=root,
+                              env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                                       HSA_ENABLE_IPC_MODE_LEGACY="0")) for r in range(2)]
+    for pr in procs:
+        assert pr.wait(timeout=900) == 0
+    res = [torch.load(f"{out}.{r}", weights_only=True) for r in range(2)]
+    cfg = cases.small_config()
+    C.set_seed(42)
+    gen, disc = C.build_models(cfg, "cpu")
+    single = C.CutTrainer(gen, disc, cfg, T.BG, T.S, device=DEV, amp=False, ops=HipOps(torch.device(DEV)))
+    photos, monets = T._inputs()
+    ref_losses = single.train_step(0, photos.to(DEV), monets.to(DEV), T._global_randomness(T._make(T.BG)))
+    torch.cuda.synchronize()
+    assert torch.equal(res[0]["flat_g"], res[1]["flat_g"]) and torch.equal(res[0]["flat_gd"], res[1]["flat_gd"])   # both ranks hold the same sum
+    assert T._grad_err(res[0]["flat_g"], single.opt_G.flat_g.cpu()) < 1e-3
+    assert T._grad_err(res[0]["flat_gd"], single.opt_D.flat_g.cpu()) < 1e-3
+    for k in ("d_loss", "g_adv", "nce", "identity", "r1"):
+        np.testing.assert_allclose(0.5 * (res[0]["losses"][k] + res[1]["losses"][k]), ref_losses[k], rtol=1e-3, atol=1e-4, err_msg=k)
+
+
+def test_inference_chain_vs_oracle(tmp_path):
+    """SURVEY §8f-2 on the GPU (generate_folder.py:125-205, 183-185): a reference-layout checkpoint whose `ema_G.shadow` differs from
+    `generator` -> inference.load_generator (EMA preferred) -> stylize on HIP must equal the oracle's generator_forward of the EMA weights
+    -> clamp -> *0.5+0.5 -> *255 -> round within +-1 LSB (fp32 operands; bf16 within +-3)."""
+    from gan_variant_research_amd import cut as C, inference as I
+    from oracle import cut_ref
+    C.set_seed(5)
+    G = C.ResNetGenerator(3, 3, 64, 9)
+    shadow = {k: (v.detach() * 0.9).clone() for k, v in G.state_dict().items()}
+    ck = tmp_path / "ckpt_final.pt"
+    torch.save({"step": 3, "generator": G.state_dict(), "discriminator": {}, "opt_G": {}, "opt_D": {}, "metrics": {}, "config": {},
+                "ema_G": {"decay": 0.999, "shadow": shadow}, "scaler": {}}, ck)
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(8)) * 2 - 1
+    want = cut_ref.generator_forward(shadow, x).detach()
+    want = (want.clamp(-1, 1) * 0.5 + 0.5).mul(255).round()
+    for bf16, lsb in ((False, 1), (True, 3)):
+        G2 = I.load_generator(str(ck), device=DEV, bf16=bf16)
+        for k, v in G2.state_dict().items():
+            assert torch.equal(v.cpu(), shadow[k]), k
+        u8 = I.stylize(G2, x.to(DEV))
+        assert u8.dtype == torch.uint8 and u8.is_cuda and tuple(u8.shape) == (2, 3, 64, 64)
+        assert int((u8.cpu().float() - want).abs().max()) <= lsb, (bf16, int((u8.cpu().float() - want).abs().max()))
+
+
 def test_inference_graph_replay_equals_eager():
     """Forward-only passes of a module with use_graph=True are captured once per input shape and replayed as one hipGraph launch:
     same bits as the eager launches, also after the weights changed (the graph reads the refreshed operand copies)."""

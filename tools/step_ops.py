@@ -53,7 +53,7 @@ for pname in ["prog_gfwd", "prog_d_compute", "prog_d_update", "prog_g_features",
                 fl = 2.0 * c.B * c.Ho * c.Wo * c.N * c.Cx * c.ntaps
             else:
                 key = f"{kind} B{c.B} {c.Ho}x{c.Wo} Cin{c.Cin} Nst{c.Nst} taps{c.ntaps} s{c.in_sy} act{c.act}{' mask' if c.mask is not None else ''}"
-                fl = 2.0 * c.B * c.Ho * c.Wo * c.Nst * c.Cin * c.ntaps * getattr(c, "flop_scale", 1.0)
+                fl = c.alg_flops()
         else:
             key, fl = getattr(op, "__name__", "op"), 0.0
         r = rows.setdefault((pname, key), [0, 0.0, 0.0])
