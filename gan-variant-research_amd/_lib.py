@@ -81,6 +81,9 @@ PROTOTYPES = {
     "gan_in_stats": (C.c_int, [PV, f32, vp, vp, vp]),
     "gan_in_finalize": (C.c_int, [vp, C.c_int, C.c_int, f32, vp]),
     "gan_in_apply": (C.c_int, [PV, vp, C.c_int, PV, PV, C.c_int, vp]),
+    "gan_in_partial_count": (C.c_int, [PV]),
+    "gan_in_partial": (C.c_int, [PV, vp, vp]),
+    "gan_in_apply_parts": (C.c_int, [PV, vp, C.c_int, f32, vp, C.c_int, PV, PV, C.c_int, vp]),
     "gan_in_bwd": (C.c_int, [PV, vp, C.c_int, PV, C.c_int, PV, PV, vp, vp]),
     "gan_in_bwd_bias": (C.c_int, [PV, vp, C.c_int, PV, C.c_int, PV, PV, vp, vp, C.c_int, C.c_int, vp]),
     "gan_fold_add": (C.c_int, [PV, PV, C.c_int, PV, vp]),

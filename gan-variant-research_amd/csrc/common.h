@@ -60,6 +60,26 @@ template <> struct Chunk<bf16_t> {
   }
 };
 
+// The same chunk as a raw 16-byte register quad (Raw<T>: f32x4 for fp32, u32x4 for bf16 -- each type is loaded as what it is): a
+// kernel that keeps U pixels in flight issues its U loads back to back with ldraw() and converts with cvtraw() only when it
+// computes, so that nothing between the loads waits for memory.
+template <typename T> struct RawOf;
+template <> struct RawOf<float> { typedef f32x4_t type; };
+template <> struct RawOf<bf16_t> { typedef u32x4_t type; };
+template <typename T> using Raw = typename RawOf<T>::type;
+template <typename T> __device__ __forceinline__ Raw<T> ldraw(const T* p) { return *reinterpret_cast<const Raw<T>*>(p); }
+template <typename T> __device__ __forceinline__ void cvtraw(const Raw<T>& t, float* v);
+template <> __device__ __forceinline__ void cvtraw<float>(const f32x4_t& t, float* v) {
+  v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+template <> __device__ __forceinline__ void cvtraw<bf16_t>(const u32x4_t& t, float* v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __builtin_bit_cast(float, t[i] << 16);
+    v[2 * i + 1] = __builtin_bit_cast(float, t[i] & 0xffff0000u);
+  }
+}
+
 template <typename T> __device__ __forceinline__ float ld1(const T* p);
 template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf2f(*p); }

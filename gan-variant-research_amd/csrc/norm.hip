@@ -8,12 +8,16 @@
 // consecutive chunks of a pixel (halo-NHWC rows are contiguous), statistics accumulate in fp32 and are
 // combined in fp64.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
 
 constexpr int NTHR = 256;
-constexpr int MAXCH = 96;  // max row-chunks per image for the two-stage statistics
+constexpr int MAXPARTS = 16;  // partials per image that the apply passes sum themselves (no finalize launch)
+// UNR (template parameter of the streaming kernels): pixels in flight per thread.  The HBM-bound passes keep UNR x (operands) x 16 B per
+// thread outstanding, so that they still stream when an MFMA-bound kernel on another stream leaves them only one block per CU.
+constexpr int MAXCH = 96;  // max row-chunks per image for the two-stage statistics (gan_in_stats: partial + finalize launch)
 
 // thread -> (chunk lane cl in [0,CL), row lane rl in [0,RL)), CL = C/EPC (power of two <= 256)
 template <typename T> struct Lanes {
@@ -38,42 +42,9 @@ struct Off {
   __device__ __forceinline__ void advance(int wraps) { o += dstep + wraps * dwrap; }
 };
 
-// sum of the padded-domain gradient over the reflect pre-images of logical pixel (y,x); pad = g.y0
-template <typename T>
-__device__ __forceinline__ void load_folded(const DView& g, int fold, int b, int y, int x, int64_t off, int cofs, float* v) {
-  constexpr int N = Chunk<T>::N;
-  const T* p = reinterpret_cast<const T*>(g.ptr);
-  Chunk<T>::load(p + off + cofs, v);   // off = g.pix(b, y, x), maintained incrementally by the caller
-  if (!fold) return;
-  // mirror partners in the padded domain (-1: none).  Nearly every pixel has none: one compare pair, no extra loads.
-  const int py = g.y0, px = g.x0;
-  int y2 = -1, x2 = -1;
-  if (y >= 1 && y <= py) y2 = py - y;
-  else if (y >= g.H - 1 - py && y <= g.H - 2) y2 = 2 * (g.H - 1) - y + py;
-  if (x >= 1 && x <= px) x2 = px - x;
-  else if (x >= g.W - 1 - px && x <= g.W - 2) x2 = 2 * (g.W - 1) - x + px;
-  if ((y2 & x2) < 0 && (y2 | x2) < 0) return;   // both -1
-  float t[N];
-  if (x2 >= 0) {
-    Chunk<T>::load(p + g.pixp(b, y + py, x2) + cofs, t);
-#pragma unroll
-    for (int e = 0; e < N; ++e) v[e] += t[e];
-  }
-  if (y2 >= 0) {
-    Chunk<T>::load(p + g.pixp(b, y2, x + px) + cofs, t);
-#pragma unroll
-    for (int e = 0; e < N; ++e) v[e] += t[e];
-    if (x2 >= 0) {
-      Chunk<T>::load(p + g.pixp(b, y2, x2) + cofs, t);
-#pragma unroll
-      for (int e = 0; e < N; ++e) v[e] += t[e];
-    }
-  }
-}
-
 // ------------------------------------------------------------------ forward statistics
 // ws[((b*nch + ch)*C + c)*2 + {0,1}] = partial (sum, sum of squares)
-template <typename T>
+template <typename T, int UNR>
 __global__ __launch_bounds__(NTHR) void in_partial_kernel(DView x, int nch, float* __restrict__ ws) {
   constexpr int N = Chunk<T>::N;
   Lanes<T> L(x.C);
@@ -85,11 +56,22 @@ __global__ __launch_bounds__(NTHR) void in_partial_kernel(DView x, int nch, floa
   for (int e = 0; e < N; ++e) s[e] = q[e] = 0.f;
   int y, xx; pixel_yx(p0 + L.rl, x.W, y, xx);
   Off ox(x, b, y, xx, L.RL, x.W);
-  for (int p = p0 + L.rl; p < p1; p += L.RL, ox.advance(pixel_step(L.RL, x.W, y, xx))) {
-    float v[N];
-    Chunk<T>::load(xp + ox.o + L.cl * N, v);
+  for (int p = p0 + L.rl; p < p1; p += 2 * UNR * L.RL) {
+    Raw<T> xr[2 * UNR];
 #pragma unroll
-    for (int e = 0; e < N; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+    for (int u = 0; u < 2 * UNR; ++u) {
+      if (p + u * L.RL < p1) xr[u] = ldraw(xp + ox.o + L.cl * N);
+      ox.advance(pixel_step(L.RL, x.W, y, xx));
+    }
+#pragma unroll
+    for (int u = 0; u < 2 * UNR; ++u) {
+      if (p + u * L.RL < p1) {
+        float v[N];
+        cvtraw<T>(xr[u], v);
+#pragma unroll
+        for (int e = 0; e < N; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+      }
+    }
   }
   __shared__ float sh[NTHR * 16];
 #pragma unroll
@@ -140,167 +122,268 @@ __global__ void in_finalize_inplace_kernel(float* __restrict__ stats, int BC, in
   stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// ------------------------------------------------------------------ per-image sums from partials (fused "finalize")
+// A consumer block turns the per-(image, chunk) partial pairs [B][nparts][C][2] into per-channel values itself: thread t adds the
+// nparts pairs of channels t, t + NTHR, ... in fp64 and in chunk order (deterministic; coalesced, every pair read once per block),
+// `fin` maps the two totals to two floats, and the block's lanes pick their N channels up from LDS.  With <= MAXPARTS partials per
+// image this replaces the separate 5 us finalize launch (+ its launch boundary) in front of every apply pass.
+constexpr int SUMS_MAXC = 1024;   // channels the LDS exchange holds (2 floats each)
+template <int N, typename Fin>
+__device__ __forceinline__ void block_sums(const float* __restrict__ parts, int nparts, int C, int b, int c0, float* sh, float* a, float* bb, Fin fin) {
+  for (int c = threadIdx.x; c < C; c += NTHR) {
+    const float2* p = reinterpret_cast<const float2*>(parts + ((int64_t)b * nparts * C + c) * 2);
+    double s = 0.0, q = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < nparts; ++k) { const float2 t = p[(int64_t)k * C]; s += t.x; q += t.y; }
+    float2 r;
+    fin(c, s, q, r.x, r.y);
+    reinterpret_cast<float2*>(sh)[c] = r;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < N; ++e) { a[e] = sh[2 * (c0 + e)]; bb[e] = sh[2 * (c0 + e) + 1]; }
+  __syncthreads();   // sh is reused by the caller
+}
+
 // ------------------------------------------------------------------ forward apply (+act, +residual, +halo)
-// iterates the padded domain when halo_mode == REFLECT, else the interior
-template <typename T>
-__global__ __launch_bounds__(NTHR) void in_apply_kernel(DView x, const float* __restrict__ stats, int act, DView res, int has_res, DView y,
-                                                       int halo_mode, int nblk) {
+// iterates the padded domain when halo_mode == REFLECT, else the interior.  Statistics: `stats` (mean, rstd) as given, or -- when
+// `parts` is set -- computed here from the partial sums (sum, sum of squares) and written to `stats` by the image's first block
+// (the backward reads them).
+template <typename T, int UNR>
+__global__ __launch_bounds__(NTHR) void in_apply_kernel(DView x, float* __restrict__ stats, const float* __restrict__ parts, int nparts, float eps,
+                                                       int act, DView res, int has_res, DView y, int halo_mode, int nblk) {
   constexpr int N = Chunk<T>::N;
   Lanes<T> L(x.C);
-  const int b = blockIdx.y;
+  const int b = blockIdx.y, cofs = L.cl * N;
   const bool padded = halo_mode == GAN_HALO_REFLECT;
   const int DH = padded ? y.H + 2 * y.y0 : y.H, DW = padded ? y.W + 2 * y.x0 : y.W, total = DH * DW;
   const int per = (total + nblk - 1) / nblk, p0 = blockIdx.x * per, p1 = min(total, p0 + per);
   float mean[N], rstd[N];
+  if (parts) {
+    __shared__ float sh[2 * SUMS_MAXC];
+    const double HW = (double)(x.H * x.W);
+    const bool first = blockIdx.x == 0;
+    block_sums<N>(parts, nparts, x.C, b, cofs, sh, mean, rstd, [&](int c, double s, double q, float& m_out, float& r_out) {
+      const double m = s / HW;
+      double var = q / HW - m * m;
+      if (var < 0) var = 0;
+      m_out = (float)m;
+      r_out = (float)(1.0 / sqrt(var + (double)eps));
+      if (first) { stats[((int64_t)b * x.C + c) * 2] = m_out; stats[((int64_t)b * x.C + c) * 2 + 1] = r_out; }
+    });
+  } else {
 #pragma unroll
-  for (int e = 0; e < N; ++e) {
-    mean[e] = stats[((int64_t)b * x.C + L.cl * N + e) * 2];
-    rstd[e] = stats[((int64_t)b * x.C + L.cl * N + e) * 2 + 1];
+    for (int e = 0; e < N; ++e) {
+      mean[e] = stats[((int64_t)b * x.C + cofs + e) * 2];
+      rstd[e] = stats[((int64_t)b * x.C + cofs + e) * 2 + 1];
+    }
   }
   const T* xp = reinterpret_cast<const T*>(x.ptr);
   const T* rp = reinterpret_cast<const T*>(res.ptr);
   T* yp = reinterpret_cast<T*>(y.ptr);
   int dy, dx; pixel_yx(p0 + L.rl, DW, dy, dx);
-  for (int p = p0 + L.rl; p < p1; p += L.RL, pixel_step(L.RL, DW, dy, dx)) {
-    int sy = dy, sx = dx;
-    if (padded) { sy = reflect_idx(dy - y.y0, y.H); sx = reflect_idx(dx - y.x0, y.W); }
-    float v[N];
-    Chunk<T>::load(xp + x.pix(b, sy, sx) + L.cl * N, v);
+  for (int p = p0 + L.rl; p < p1; p += UNR * L.RL) {
+    Raw<T> xr[UNR], rr[UNR];
+    int64_t oo[UNR];
 #pragma unroll
-    for (int e = 0; e < N; ++e) v[e] = act_apply((v[e] - mean[e]) * rstd[e], act);
-    if (has_res) {
-      float r[N];
-      Chunk<T>::load(rp + res.pix(b, sy, sx) + L.cl * N, r);
-#pragma unroll
-      for (int e = 0; e < N; ++e) v[e] += r[e];
+    for (int u = 0; u < UNR; ++u) {
+      if (p + u * L.RL < p1) {
+        int sy = dy, sx = dx;
+        if (padded) { sy = reflect_idx(dy - y.y0, y.H); sx = reflect_idx(dx - y.x0, y.W); }
+        xr[u] = ldraw(xp + x.pix(b, sy, sx) + cofs);
+        if (has_res) rr[u] = ldraw(rp + res.pix(b, sy, sx) + cofs);
+        oo[u] = padded ? y.pixp(b, dy, dx) : y.pix(b, dy, dx);
+      }
+      pixel_step(L.RL, DW, dy, dx);
     }
-    const int64_t o = padded ? y.pixp(b, dy, dx) : y.pix(b, dy, dx);
-    Chunk<T>::store(yp + o + L.cl * N, v);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (p + u * L.RL < p1) {
+        float v[N];
+        cvtraw<T>(xr[u], v);
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = act_apply((v[e] - mean[e]) * rstd[e], act);
+        if (has_res) {
+          float r[N];
+          cvtraw<T>(rr[u], r);
+#pragma unroll
+          for (int e = 0; e < N; ++e) v[e] += r[e];
+        }
+        Chunk<T>::store(yp + oo[u] + cofs, v);
+      }
+    }
   }
 }
 
 // ------------------------------------------------------------------ backward
-template <typename T>
-__device__ __forceinline__ void in_bwd_g(const DView& x, const float* mean, const float* rstd, int act, const DView& gy, int fold,
-                                         const DView& g2, int has_g2, int b, int yy, int xx, int cofs, int64_t offx, int64_t offg,
-                                         int64_t offg2, float* g, float* xh) {
-  constexpr int N = Chunk<T>::N;
-  Chunk<T>::load(reinterpret_cast<const T*>(x.ptr) + offx + cofs, xh);
-  load_folded<T>(gy, fold, b, yy, xx, offg, cofs, g);
-  if (has_g2) {
-    float t[N];
-    Chunk<T>::load(reinterpret_cast<const T*>(g2.ptr) + offg2 + cofs, t);
-#pragma unroll
-    for (int e = 0; e < N; ++e) g[e] += t[e];
-  }
-#pragma unroll
-  for (int e = 0; e < N; ++e) {
-    xh[e] = (xh[e] - mean[e]) * rstd[e];
-    if (act == GAN_ACT_RELU) g[e] = xh[e] > 0.f ? g[e] : 0.f;
-    else if (act == GAN_ACT_LRELU) g[e] = xh[e] > 0.f ? g[e] : 0.2f * g[e];
-  }
+// The backward passes run beside the weight-gradient kernels of the second stream, whose persistent blocks leave a CU 80 registers
+// per SIMD lane and 16 KB of LDS: these kernels are written to fit into that (one 256-thread block per CU then streams with
+// UNR x 2 x 16 B per thread in flight).  Hence: 32-bit offsets relative to the image, statistics folded into per-channel
+// coefficients (no xhat in the loop), activation / fold as template parameters, 8 KB of LDS.
+struct Off32 {   // element offset of the walk's current pixel inside ONE image of a view
+  int o, dstep, dwrap;
+  __device__ __forceinline__ Off32(const DView& v, int y, int x, int step, int W)
+      : o(((y + v.y0) * v.Wp + x + v.x0) * v.C), dstep(step * v.C), dwrap((v.Wp - W) * v.C) {}
+  __device__ __forceinline__ void advance(int wraps) { o += dstep + wraps * dwrap; }
+};
+template <typename T> __device__ __forceinline__ const T* image_ptr(const DView& v, int b, int cofs) {
+  return reinterpret_cast<const T*>(v.ptr) + (int64_t)b * v.Hp * v.Wp * v.C + cofs;
 }
 
+// adds the reflect pre-images of logical pixel (y,x) (pad = g.y0) to v: the fold of a padded-domain gradient.  gp = image_ptr of g.
+// Nearly every pixel has none: one compare pair, no loads.
 template <typename T>
-__global__ __launch_bounds__(NTHR) void in_bwd_partial_kernel(DView x, const float* __restrict__ stats, int act, DView gy, int fold, DView g2,
-                                                             int has_g2, int nch, float* __restrict__ ws) {
+__device__ __forceinline__ void fold_extra(const DView& g, const T* gp, int y, int x, float* v) {
   constexpr int N = Chunk<T>::N;
-  Lanes<T> L(x.C);
-  const int b = blockIdx.y, ch = blockIdx.x, HW = x.H * x.W;
-  const int per = (HW + nch - 1) / nch, p0 = ch * per, p1 = min(HW, p0 + per);
-  float mean[N], rstd[N], s1[N], s2[N];
+  const int py = g.y0, px = g.x0;
+  int y2 = -1, x2 = -1;
+  if (y >= 1 && y <= py) y2 = py - y;
+  else if (y >= g.H - 1 - py && y <= g.H - 2) y2 = 2 * (g.H - 1) - y + py;
+  if (x >= 1 && x <= px) x2 = px - x;
+  else if (x >= g.W - 1 - px && x <= g.W - 2) x2 = 2 * (g.W - 1) - x + px;
+  if ((y2 & x2) < 0 && (y2 | x2) < 0) return;   // both -1
+  float t[N];
+  if (x2 >= 0) {
+    Chunk<T>::load(gp + ((y + py) * g.Wp + x2) * g.C, t);
 #pragma unroll
-  for (int e = 0; e < N; ++e) {
-    mean[e] = stats[((int64_t)b * x.C + L.cl * N + e) * 2];
-    rstd[e] = stats[((int64_t)b * x.C + L.cl * N + e) * 2 + 1];
-    s1[e] = s2[e] = 0.f;
+    for (int e = 0; e < N; ++e) v[e] += t[e];
   }
-  int yy, xx; pixel_yx(p0 + L.rl, x.W, yy, xx);
-  Off ox(x, b, yy, xx, L.RL, x.W), og(gy, b, yy, xx, L.RL, x.W), o2(has_g2 ? g2 : x, b, yy, xx, L.RL, x.W);
-  for (int p = p0 + L.rl; p < p1; p += L.RL) {
-    float g[N], xh[N];
-    in_bwd_g<T>(x, mean, rstd, act, gy, fold, g2, has_g2, b, yy, xx, L.cl * N, ox.o, og.o, o2.o, g, xh);
+  if (y2 >= 0) {
+    Chunk<T>::load(gp + (y2 * g.Wp + x + px) * g.C, t);
 #pragma unroll
-    for (int e = 0; e < N; ++e) { s1[e] += g[e]; s2[e] += g[e] * xh[e]; }
-    const int wr = pixel_step(L.RL, x.W, yy, xx);
-    ox.advance(wr); og.advance(wr); o2.advance(wr);
+    for (int e = 0; e < N; ++e) v[e] += t[e];
+    if (x2 >= 0) {
+      Chunk<T>::load(gp + (y2 * g.Wp + x2) * g.C, t);
+#pragma unroll
+      for (int e = 0; e < N; ++e) v[e] += t[e];
+    }
   }
-  __shared__ float sh[NTHR * 16];
-#pragma unroll
-  for (int e = 0; e < N; ++e) { sh[(threadIdx.x * N + e) * 2] = s1[e]; sh[(threadIdx.x * N + e) * 2 + 1] = s2[e]; }
+}
+template <int ACT> __device__ __forceinline__ float act_mask(float g, float x, float mean) {   // g * act'(xhat), sign(xhat) = sign(x - mean)
+  if (ACT == GAN_ACT_RELU) return x > mean ? g : 0.f;
+  if (ACT == GAN_ACT_LRELU) return x > mean ? g : 0.2f * g;
+  return g;
+}
+// sum of v[e] over the row lanes (threads with equal cl) of the block, through 8 KB of LDS; valid in the rl == 0 threads
+template <int N, typename LanesT>
+__device__ __forceinline__ void row_lane_sum(const LanesT& L, float* sh, float* v) {
   __syncthreads();
-  if (L.rl == 0) {
+#pragma unroll
+  for (int e = 0; e < N; ++e) sh[threadIdx.x * N + e] = v[e];
+  __syncthreads();
+  if (L.rl == 0)
     for (int r = 1; r < L.RL; ++r)
 #pragma unroll
-      for (int e = 0; e < N; ++e) {
-        s1[e] += sh[((r * L.CL + L.cl) * N + e) * 2];
-        s2[e] += sh[((r * L.CL + L.cl) * N + e) * 2 + 1];
+      for (int e = 0; e < N; ++e) v[e] += sh[(r * L.CL + L.cl) * N + e];
+}
+
+// ws[((b*nch + ch)*C + c)*2 + {0,1}] = partial (sum g', sum g'*x) of chunk ch over its pixels, g' = act'-masked (folded) gradient and
+// x the RAW norm input: the apply pass turns the totals into mean(g') and mean(g'*xhat) = rstd * (S2 - mean * S1) / HW in fp64
+template <typename T, int UNR, int ACT, bool FOLD>
+__global__ __launch_bounds__(NTHR) void in_bwd_partial_kernel(DView x, const float* __restrict__ stats, DView gy, int nch, float* __restrict__ ws) {
+  constexpr int N = Chunk<T>::N;
+  Lanes<T> L(x.C);
+  const int b = blockIdx.y, ch = blockIdx.x, HW = x.H * x.W, cofs = L.cl * N;
+  const int per = (HW + nch - 1) / nch, p0 = ch * per, p1 = min(HW, p0 + per);
+  float mean[N], s1[N], s2[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    mean[e] = ACT == GAN_ACT_NONE ? 0.f : stats[((int64_t)b * x.C + cofs + e) * 2];
+    s1[e] = s2[e] = 0.f;
+  }
+  const T *xp = image_ptr<T>(x, b, cofs), *gp = image_ptr<T>(gy, b, cofs);
+  int yy, xx; pixel_yx(p0 + L.rl, x.W, yy, xx);
+  Off32 ox(x, yy, xx, L.RL, x.W), og(gy, yy, xx, L.RL, x.W);
+  for (int p = p0 + L.rl; p < p1; p += UNR * L.RL) {
+    Raw<T> xr[UNR], gr[UNR];
+    int ys[UNR], xs[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (FOLD) { ys[u] = yy; xs[u] = xx; }
+      if (p + u * L.RL < p1) { xr[u] = ldraw(xp + ox.o); gr[u] = ldraw(gp + og.o); }
+      const int wr = pixel_step(L.RL, x.W, yy, xx);
+      ox.advance(wr); og.advance(wr);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (p + u * L.RL < p1) {
+        float g[N], xv[N];
+        cvtraw<T>(gr[u], g);
+        if (FOLD) fold_extra<T>(gy, gp, ys[u], xs[u], g);
+        cvtraw<T>(xr[u], xv);
+#pragma unroll
+        for (int e = 0; e < N; ++e) { const float gm = act_mask<ACT>(g[e], xv[e], mean[e]); s1[e] += gm; s2[e] += gm * xv[e]; }
       }
-    float* o = ws + ((int64_t)(b * nch + ch) * x.C + L.cl * N) * 2;
+    }
+  }
+  __shared__ float sh[NTHR * 8];
+  row_lane_sum<N>(L, sh, s1);
+  row_lane_sum<N>(L, sh, s2);
+  if (L.rl == 0) {
+    float* o = ws + ((int64_t)(b * nch + ch) * x.C + cofs) * 2;
 #pragma unroll
     for (int e = 0; e < N; ++e) { o[2 * e] = s1[e]; o[2 * e + 1] = s2[e]; }
   }
 }
-// ws2[(b*C+c)*2] = mean(g), +1 = mean(g*xhat)
-__global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const float* __restrict__ ws, int nch, int C, int BC, int HW, float* __restrict__ ws2) {
-  const int i = blockIdx.x * 32 + (threadIdx.x & 31), k0 = threadIdx.x >> 5;
-  double s = 0, q = 0;
-  if (i < BC) {
-    const int b = i / C, c = i - b * C;
-    for (int k = k0; k < nch; k += 8) {
-      const float* p = ws + ((int64_t)(b * nch + k) * C + c) * 2;
-      s += p[0]; q += p[1];
-    }
-  }
-  __shared__ double sh[512];
-  sh[threadIdx.x * 2] = s; sh[threadIdx.x * 2 + 1] = q;
-  __syncthreads();
-  if (k0 == 0 && i < BC) {
-    for (int k = 1; k < 8; ++k) { s += sh[(k * 32 + threadIdx.x) * 2]; q += sh[(k * 32 + threadIdx.x) * 2 + 1]; }
-    ws2[2 * i] = (float)(s / HW);
-    ws2[2 * i + 1] = (float)(q / HW);
-  }
-}
-template <typename T>
-__global__ __launch_bounds__(NTHR) void in_bwd_apply_kernel(DView x, const float* __restrict__ stats, int act, DView gy, int fold, DView g2,
-                                                           int has_g2, const float* __restrict__ ws2, DView dx, int nblk,
-                                                           float* __restrict__ bias_part) {
+// dx = rstd * (g' - mean(g') - xhat * mean(g'*xhat)) = g' * A + x * Bc + Cc with per-channel A = rstd, Bc = -rstd^2 m2, Cc = -rstd m1 +
+// rstd^2 m2 mean, computed once per block (fp64) from the nch partials of in_bwd_partial_kernel.
+// bias_part (optional): this block's row of the bias-gradient partials.  The gradient of a bias in front of a non-affine InstanceNorm is
+// the column sum of dx, which is IDENTICALLY zero: sum_p dx = A S1 + Bc HW mean + HW Cc = rstd S1 - HW rstd (S1 / HW).  The reference's
+// autograd value is the rounding noise of that sum (|g| ~ 1e-9); here the sum is evaluated in closed form from the
+// same totals (fp64) by the image's first block -- the other blocks' rows are zero -- instead of being re-accumulated per element.
+template <typename T, int UNR, int ACT, bool FOLD>
+__global__ __launch_bounds__(NTHR) void in_bwd_apply_kernel(DView x, const float* __restrict__ stats, DView gy, const float* __restrict__ ws, int nch,
+                                                           DView dx, int nblk, float* __restrict__ bias_part) {
   constexpr int N = Chunk<T>::N;
   Lanes<T> L(x.C);
-  const int b = blockIdx.y, HW = x.H * x.W;
+  const int b = blockIdx.y, HW = x.H * x.W, cofs = L.cl * N;
   const int per = (HW + nblk - 1) / nblk, p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
-  float mean[N], rstd[N], m1[N], m2[N], bs[N];
-#pragma unroll
-  for (int e = 0; e < N; ++e) bs[e] = 0.f;
-#pragma unroll
-  for (int e = 0; e < N; ++e) {
-    const int64_t i = (int64_t)b * x.C + L.cl * N + e;
-    mean[e] = stats[2 * i]; rstd[e] = stats[2 * i + 1]; m1[e] = ws2[2 * i]; m2[e] = ws2[2 * i + 1];
-  }
-  T* dp = reinterpret_cast<T*>(dx.ptr);
-  int yy, xx; pixel_yx(p0 + L.rl, x.W, yy, xx);
-  Off ox(x, b, yy, xx, L.RL, x.W), og(gy, b, yy, xx, L.RL, x.W), o2(has_g2 ? g2 : x, b, yy, xx, L.RL, x.W), od(dx, b, yy, xx, L.RL, x.W);
-  for (int p = p0 + L.rl; p < p1; p += L.RL) {
-    float g[N], xh[N];
-    in_bwd_g<T>(x, mean, rstd, act, gy, fold, g2, has_g2, b, yy, xx, L.cl * N, ox.o, og.o, o2.o, g, xh);
-#pragma unroll
-    for (int e = 0; e < N; ++e) { g[e] = rstd[e] * (g[e] - m1[e] - xh[e] * m2[e]); bs[e] += g[e]; }
-    Chunk<T>::store(dp + od.o + L.cl * N, g);
-    const int wr = pixel_step(L.RL, x.W, yy, xx);
-    ox.advance(wr); og.advance(wr); o2.advance(wr); od.advance(wr);
-  }
-  if (bias_part) {   // column sums of dx = gradient of the conv bias in front of this norm: partial per block
-    __shared__ float sh[NTHR * 8];
-#pragma unroll
-    for (int e = 0; e < N; ++e) sh[threadIdx.x * N + e] = bs[e];
+  __shared__ float sh[NTHR * 8];
+  float mean[N], A[N], Bc[N], Cc[N];
+  {
+    f32x4_t* sh4 = reinterpret_cast<f32x4_t*>(sh);        // [C] x (mean, A, Bc, Cc); C <= SUMS_MAXC = NTHR * 8 / 4
+    for (int c = threadIdx.x; c < x.C; c += NTHR) {
+      const float2* pp = reinterpret_cast<const float2*>(ws + ((int64_t)b * nch * x.C + c) * 2);
+      double S1 = 0.0, S2 = 0.0;
+#pragma unroll 8
+      for (int k = 0; k < nch; ++k) { const float2 t = pp[(int64_t)k * x.C]; S1 += t.x; S2 += t.y; }
+      const double mu = stats[((int64_t)b * x.C + c) * 2], rs = stats[((int64_t)b * x.C + c) * 2 + 1];
+      const double m1 = S1 / HW, m2 = rs * (S2 - mu * S1) / HW;
+      const double bcd = -rs * rs * m2, ccd = -rs * m1 + rs * rs * m2 * mu;
+      const f32x4_t r = {(float)mu, (float)rs, (float)bcd, (float)ccd};
+      sh4[c] = r;
+      if (bias_part) bias_part[(int64_t)(b * nblk + blockIdx.x) * x.C + c] = blockIdx.x == 0 ? (float)(rs * S1 + bcd * (HW * mu) + HW * ccd) : 0.f;
+    }
     __syncthreads();
-    if (L.rl == 0) {
-      for (int r = 1; r < L.RL; ++r)
 #pragma unroll
-        for (int e = 0; e < N; ++e) bs[e] += sh[(r * L.CL + L.cl) * N + e];
-      float* o = bias_part + (int64_t)(b * nblk + blockIdx.x) * x.C + L.cl * N;
+    for (int e = 0; e < N; ++e) { const f32x4_t r = sh4[cofs + e]; mean[e] = r[0]; A[e] = r[1]; Bc[e] = r[2]; Cc[e] = r[3]; }
+  }
+  const T *xp = image_ptr<T>(x, b, cofs), *gp = image_ptr<T>(gy, b, cofs);
+  T* dp = const_cast<T*>(image_ptr<T>(dx, b, cofs));
+  int yy, xx; pixel_yx(p0 + L.rl, x.W, yy, xx);
+  Off32 ox(x, yy, xx, L.RL, x.W), og(gy, yy, xx, L.RL, x.W), od(dx, yy, xx, L.RL, x.W);
+  for (int p = p0 + L.rl; p < p1; p += UNR * L.RL) {
+    Raw<T> xr[UNR], gr[UNR];
+    int ys[UNR], xs[UNR], ods[UNR];
 #pragma unroll
-      for (int e = 0; e < N; ++e) o[e] = bs[e];
+    for (int u = 0; u < UNR; ++u) {
+      if (FOLD) { ys[u] = yy; xs[u] = xx; }
+      ods[u] = od.o;
+      if (p + u * L.RL < p1) { xr[u] = ldraw(xp + ox.o); gr[u] = ldraw(gp + og.o); }
+      const int wr = pixel_step(L.RL, x.W, yy, xx);
+      ox.advance(wr); og.advance(wr); od.advance(wr);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (p + u * L.RL < p1) {
+        float g[N], xv[N];
+        cvtraw<T>(gr[u], g);
+        if (FOLD) fold_extra<T>(gy, gp, ys[u], xs[u], g);
+        cvtraw<T>(xr[u], xv);
+#pragma unroll
+        for (int e = 0; e < N; ++e) g[e] = act_mask<ACT>(g[e], xv[e], mean[e]) * A[e] + (xv[e] * Bc[e] + Cc[e]);
+        Chunk<T>::store(dp + ods[u], g);
+      }
     }
   }
 }
@@ -352,34 +435,50 @@ __global__ __launch_bounds__(1024) void bias_finalize_batch_kernel(const gan_bia
 }
 
 // out = a + fold(b)   /   dx = (fold(g) + g2) * act'(y)
-template <typename T>
-__global__ __launch_bounds__(NTHR) void fold_add_kernel(DView a, int has_a, DView g, int fold, DView y, int act, DView out, int nblk) {
+template <typename T, int UNR, bool FOLD>
+__global__ __launch_bounds__(NTHR) void fold_add_kernel(DView a, int has_a, DView g, DView y, int act, DView out, int nblk) {
   constexpr int N = Chunk<T>::N;
   Lanes<T> L(out.C);
-  const int b = blockIdx.y, HW = out.H * out.W;
+  const int b = blockIdx.y, HW = out.H * out.W, cofs = L.cl * N;
   const int per = (HW + nblk - 1) / nblk, p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
-  T* op = reinterpret_cast<T*>(out.ptr);
+  const bool has_y = act != GAN_ACT_NONE;
+  const T *gp = image_ptr<T>(g, b, cofs), *ap = image_ptr<T>(has_a ? a : g, b, cofs), *yp = image_ptr<T>(has_y ? y : g, b, cofs);
+  T* op = const_cast<T*>(image_ptr<T>(out, b, cofs));
   int yy, xx; pixel_yx(p0 + L.rl, out.W, yy, xx);
-  Off og(g, b, yy, xx, L.RL, out.W), oa(has_a ? a : g, b, yy, xx, L.RL, out.W), oy(act != GAN_ACT_NONE ? y : g, b, yy, xx, L.RL, out.W),
-      oo(out, b, yy, xx, L.RL, out.W);
-  for (int p = p0 + L.rl; p < p1; p += L.RL) {
-    float v[N];
-    load_folded<T>(g, fold, b, yy, xx, og.o, L.cl * N, v);
-    if (has_a) {
-      float t[N];
-      Chunk<T>::load(reinterpret_cast<const T*>(a.ptr) + oa.o + L.cl * N, t);
+  Off32 og(g, yy, xx, L.RL, out.W), oa(has_a ? a : g, yy, xx, L.RL, out.W), oy(has_y ? y : g, yy, xx, L.RL, out.W), oo(out, yy, xx, L.RL, out.W);
+  for (int p = p0 + L.rl; p < p1; p += UNR * L.RL) {
+    Raw<T> gr[UNR], ar[UNR];
+    int ys[UNR], xs[UNR], os[UNR], oys[UNR];
 #pragma unroll
-      for (int e = 0; e < N; ++e) v[e] += t[e];
+    for (int u = 0; u < UNR; ++u) {
+      if (FOLD) { ys[u] = yy; xs[u] = xx; }
+      os[u] = oo.o; oys[u] = oy.o;
+      if (p + u * L.RL < p1) {
+        gr[u] = ldraw(gp + og.o);
+        if (has_a) ar[u] = ldraw(ap + oa.o);
+      }
+      const int wr = pixel_step(L.RL, out.W, yy, xx);
+      og.advance(wr); oa.advance(wr); oy.advance(wr); oo.advance(wr);
     }
-    if (act != GAN_ACT_NONE) {
-      float t[N];
-      Chunk<T>::load(reinterpret_cast<const T*>(y.ptr) + oy.o + L.cl * N, t);
 #pragma unroll
-      for (int e = 0; e < N; ++e) v[e] *= act_grad_from_out(t[e], act);
+    for (int u = 0; u < UNR; ++u) {
+      if (p + u * L.RL < p1) {
+        float v[N], t[N];
+        cvtraw<T>(gr[u], v);
+        if (FOLD) fold_extra<T>(g, gp, ys[u], xs[u], v);
+        if (has_a) {
+          cvtraw<T>(ar[u], t);
+#pragma unroll
+          for (int e = 0; e < N; ++e) v[e] += t[e];
+        }
+        if (has_y) {
+          Chunk<T>::load(yp + oys[u], t);
+#pragma unroll
+          for (int e = 0; e < N; ++e) v[e] *= act_grad_from_out(t[e], act);
+        }
+        Chunk<T>::store(op + os[u], v);
+      }
     }
-    Chunk<T>::store(op + oo.o + L.cl * N, v);
-    const int wr = pixel_step(L.RL, out.W, yy, xx);
-    og.advance(wr); oa.advance(wr); oy.advance(wr); oo.advance(wr);
   }
 }
 
@@ -454,10 +553,19 @@ int check_lanes(const gan_view* v, const char* what) {
   return 0;
 }
 // row-chunks per image for the statistics passes: ~2048 16-byte loads per block, at most MAXCH (workspace bound)
-int work_per_block() {   // 16-byte loads per block; GAN_NORM_WORK overrides (tuning aid)
+int work_per_block() {   // 16-byte loads per block and operand; GAN_NORM_WORK overrides (tuning aid)
   static int w = 0;
-  if (!w) { const char* e = getenv("GAN_NORM_WORK"); w = e ? atoi(e) : 2048; if (w < 256) w = 256; }
+  if (!w) { const char* e = getenv("GAN_NORM_WORK"); w = e ? atoi(e) : 4096; if (w < 256) w = 256; }
   return w;
+}
+// partials per image for the passes whose consumer sums them itself (<= MAXPARTS): as many as keep ~2 blocks per CU busy
+int nparts_for(int B, int HW, int cl) {
+  int64_t n = ((int64_t)HW * cl + 2047) / 2048;       // at least 2048 loads per block
+  int64_t want = (512 + B - 1) / B;                    // ~512 blocks per launch
+  if (n > want) n = want;
+  if (n > MAXPARTS) n = MAXPARTS;
+  if (n < 1) n = 1;
+  return (int)n;
 }
 int nchunks_for(int HW, int cl) {
   const int W = work_per_block();
@@ -484,6 +592,24 @@ int fold_ok(const gan_view* g, int fold) {
 
 }  // namespace
 
+// pixels in flight per thread of the streaming kernels: 2 for the backward family (fits beside a resident weight-gradient block: <= 80
+// registers), 4 for the forward passes, which run alone.  GAN_NORM_UNR / GAN_NORM_UNR_FWD = 2 or 4 override (tuning aid, read once).
+static int norm_unroll(bool fwd) {
+  static int u[2] = {0, 0};
+  if (!u[fwd]) { const char* e = getenv(fwd ? "GAN_NORM_UNR_FWD" : "GAN_NORM_UNR"); const int v = e ? atoi(e) : (fwd ? 4 : 2); u[fwd] = v == 2 || v == 4 ? v : (fwd ? 4 : 2); }
+  return u[fwd];
+}
+#define GAN_DISPATCH_NORM_U(dt, fwd, ...)                                            \
+  {                                                                                  \
+    const int unr__ = norm_unroll(fwd);                                              \
+    if ((dt) == GAN_F32) { typedef float T;                                          \
+      if (unr__ == 2) { constexpr int U = 2; __VA_ARGS__ } else { constexpr int U = 4; __VA_ARGS__ } } \
+    else { typedef bf16_t T;                                                         \
+      if (unr__ == 2) { constexpr int U = 2; __VA_ARGS__ } else { constexpr int U = 4; __VA_ARGS__ } } \
+  }
+#define GAN_DISPATCH_NORM(dt, ...) GAN_DISPATCH_NORM_U(dt, false, __VA_ARGS__)
+#define GAN_DISPATCH_NORM_FWD(dt, ...) GAN_DISPATCH_NORM_U(dt, true, __VA_ARGS__)
+
 #define VCHK(v, name) do { if (gan_check_view(v, name)) return -1; } while (0)
 #define SAME_SHAPE(a, b, what) GAN_CHECK((a)->B == (b)->B && (a)->H == (b)->H && (a)->W == (b)->W && (a)->C == (b)->C && (a)->dtype == (b)->dtype, what ": shape/dtype mismatch")
 
@@ -495,7 +621,7 @@ extern "C" int gan_in_stats(const gan_view* x, float eps, float* stats, float* w
   const int HW = x->H * x->W, nch = nchunks_for(HW, lanes_of(x)), BC = x->B * x->C;
   DView dx = to_dview(x);
   hipStream_t s = (hipStream_t)stream;
-  GAN_DISPATCH_DTYPE(x->dtype, hipLaunchKernelGGL((in_partial_kernel<T>), dim3(nch, x->B), dim3(NTHR), 0, s, dx, nch, ws);)
+  GAN_DISPATCH_NORM_FWD(x->dtype, hipLaunchKernelGGL((in_partial_kernel<T, U>), dim3(nch, x->B), dim3(NTHR), 0, s, dx, nch, ws);)
   hipLaunchKernelGGL(in_finalize_kernel, dim3((BC + 31) / 32), dim3(256), 0, s, ws, nch, x->C, BC, HW, eps, stats);
   GAN_LAUNCH_CHECK();
   return 0;
@@ -529,8 +655,47 @@ extern "C" int gan_in_apply(const gan_view* x, const float* stats, int act, cons
   const int DH = halo_mode == GAN_HALO_REFLECT ? y->H + 2 * y->y0 : y->H, DW = halo_mode == GAN_HALO_REFLECT ? y->W + 2 * y->x0 : y->W;
   const int nblk = nblocks_for(DH * DW, lanes_of(x));
   DView dx = to_dview(x), dy = to_dview(y), dr = residual ? to_dview(residual) : null_dview();
-  GAN_DISPATCH_DTYPE(x->dtype, hipLaunchKernelGGL((in_apply_kernel<T>), dim3(nblk, x->B), dim3(NTHR), 0, (hipStream_t)stream, dx, stats, act,
-                                                  dr, residual ? 1 : 0, dy, halo_mode, nblk);)
+  GAN_DISPATCH_NORM_FWD(x->dtype, hipLaunchKernelGGL((in_apply_kernel<T, U>), dim3(nblk, x->B), dim3(NTHR), 0, (hipStream_t)stream, dx,
+                                                  const_cast<float*>(stats), (const float*)nullptr, 0, 0.f, act, dr, residual ? 1 : 0, dy, halo_mode, nblk);)
+  GAN_LAUNCH_CHECK();
+  return 0;
+}
+
+// Statistics partials of x for gan_in_apply_parts: parts = fp32 [B][gan_in_partial_count(x)][C][2] (sum, sum of squares per chunk of pixels)
+extern "C" int gan_in_partial_count(const gan_view* x) {
+  if (gan_check_view(x, "in_partial_count.x")) return -1;
+  return nparts_for(x->B, x->H * x->W, lanes_of(x));
+}
+extern "C" int gan_in_partial(const gan_view* x, float* parts, void* stream) {
+  VCHK(x, "in_partial.x");
+  if (check_lanes(x, "in_partial")) return -1;
+  GAN_CHECK(parts, "in_partial: null pointer");
+  const int nch = nparts_for(x->B, x->H * x->W, lanes_of(x));
+  DView dx = to_dview(x);
+  GAN_DISPATCH_NORM_FWD(x->dtype, hipLaunchKernelGGL((in_partial_kernel<T, U>), dim3(nch, x->B), dim3(NTHR), 0, (hipStream_t)stream, dx, nch, parts);)
+  GAN_LAUNCH_CHECK();
+  return 0;
+}
+
+// gan_in_apply with the statistics taken from per-chunk partials (gan_in_partial, or a convolution epilogue's gan_conv_desc.stats):
+// every block sums the nparts (<= 16) partial pairs of its image itself, so no finalize launch precedes the pass; the image's first
+// block also writes (mean, rstd) to `stats` for the backward pass.
+extern "C" int gan_in_apply_parts(const gan_view* x, const float* parts, int nparts, float eps, float* stats, int act, const gan_view* residual,
+                                  const gan_view* y, int halo_mode, void* stream) {
+  VCHK(x, "in_apply_parts.x"); VCHK(y, "in_apply_parts.y");
+  if (check_lanes(x, "in_apply_parts")) return -1;
+  SAME_SHAPE(x, y, "in_apply_parts(x,y)");
+  if (residual) { VCHK(residual, "in_apply_parts.residual"); SAME_SHAPE(x, residual, "in_apply_parts(x,residual)"); }
+  GAN_CHECK(parts && stats, "in_apply_parts: null pointer");
+  GAN_CHECK(nparts >= 1 && nparts <= MAXPARTS, "in_apply_parts: nparts=%d outside 1..%d (use gan_in_stats_from_parts + gan_in_apply)", nparts, MAXPARTS);
+  GAN_CHECK(x->C <= SUMS_MAXC, "in_apply_parts: C=%d > %d", x->C, SUMS_MAXC);
+  if (halo_mode == GAN_HALO_REFLECT)
+    GAN_CHECK(y->y0 < y->H && y->x0 < y->W && 2 * y->y0 + y->H <= y->Hp && 2 * y->x0 + y->W <= y->Wp, "in_apply_parts: reflect halo does not fit");
+  const int DH = halo_mode == GAN_HALO_REFLECT ? y->H + 2 * y->y0 : y->H, DW = halo_mode == GAN_HALO_REFLECT ? y->W + 2 * y->x0 : y->W;
+  const int nblk = nblocks_for(DH * DW, lanes_of(x));
+  DView dx = to_dview(x), dy = to_dview(y), dr = residual ? to_dview(residual) : null_dview();
+  GAN_DISPATCH_NORM_FWD(x->dtype, hipLaunchKernelGGL((in_apply_kernel<T, U>), dim3(nblk, x->B), dim3(NTHR), 0, (hipStream_t)stream, dx, stats, parts, nparts,
+                                                  eps, act, dr, residual ? 1 : 0, dy, halo_mode, nblk);)
   GAN_LAUNCH_CHECK();
   return 0;
 }
@@ -561,16 +726,38 @@ static int in_bwd_impl(const gan_view* x, const float* stats, int act, const gan
   if (fold_ok(gy, fold)) return -1;
   GAN_CHECK(stats && ws, "in_bwd: null pointer");
   GAN_CHECK(act == GAN_ACT_NONE || act == GAN_ACT_RELU || act == GAN_ACT_LRELU, "in_bwd: unsupported activation %d", act);
-  const int HW = x->H * x->W, nch = nchunks_for(HW, lanes_of(x)), BC = x->B * x->C;
+  GAN_CHECK(x->C <= NTHR * 8 / 4, "in_bwd: C=%d > %d", x->C, NTHR * 8 / 4);
+  // two launches: partial sums (sum g, sum g*xhat) per (image, chunk), then the apply pass, whose blocks add the <= 16 chunks up themselves
+  const int HW = x->H * x->W, nch = nparts_for(x->B, HW, lanes_of(x)), BC = x->B * x->C;
   float* ws2 = ws + (int64_t)x->B * MAXCH * x->C * 2;
   DView vx = to_dview(x), vg = to_dview(gy), v2 = g2 ? to_dview(g2) : null_dview(), vd = to_dview(dx);
   hipStream_t s = (hipStream_t)stream;
   const int nblk = nblocks_for(HW, lanes_of(x));
-  GAN_DISPATCH_DTYPE(x->dtype,
-    hipLaunchKernelGGL((in_bwd_partial_kernel<T>), dim3(nch, x->B), dim3(NTHR), 0, s, vx, stats, act, vg, fold, v2, g2 ? 1 : 0, nch, ws);
-    hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3((BC + 31) / 32), dim3(256), 0, s, ws, nch, x->C, BC, HW, ws2);
-    hipLaunchKernelGGL((in_bwd_apply_kernel<T>), dim3(nblk, x->B), dim3(NTHR), 0, s, vx, stats, act, vg, fold, v2, g2 ? 1 : 0, ws2, vd, nblk,
-                       bias_part ? bias_part : (bias_grad ? ws2 + (int64_t)BC * 2 : nullptr));)
+  float* bp = bias_part ? bias_part : (bias_grad ? ws2 + (int64_t)BC * 2 : nullptr);
+  if (g2) {   // second addend (rare: the trainers never pass one): dx <- fold(gy) + g2 first, then the norm backward in place on dx
+    GAN_DISPATCH_NORM(x->dtype,
+      if (fold) hipLaunchKernelGGL((fold_add_kernel<T, U, true>), dim3(nblk, x->B), dim3(NTHR), 0, s, v2, 1, vg, null_dview(), GAN_ACT_NONE, vd, nblk);
+      else hipLaunchKernelGGL((fold_add_kernel<T, U, false>), dim3(nblk, x->B), dim3(NTHR), 0, s, v2, 1, vg, null_dview(), GAN_ACT_NONE, vd, nblk);)
+    vg = vd;
+    fold = 0;
+  }
+  GAN_DISPATCH_NORM(x->dtype,
+    auto go = [&](auto act_c, auto fold_c) {
+      constexpr int ACT = decltype(act_c)::value;
+      constexpr bool FOLD = decltype(fold_c)::value;
+      hipLaunchKernelGGL((in_bwd_partial_kernel<T, U, ACT, FOLD>), dim3(nch, x->B), dim3(NTHR), 0, s, vx, stats, vg, nch, ws);
+      hipLaunchKernelGGL((in_bwd_apply_kernel<T, U, ACT, FOLD>), dim3(nblk, x->B), dim3(NTHR), 0, s, vx, stats, vg, ws, nch, vd, nblk, bp);
+    };
+    using std::integral_constant;
+    if (fold) {
+      if (act == GAN_ACT_RELU) go(integral_constant<int, GAN_ACT_RELU>{}, integral_constant<bool, true>{});
+      else if (act == GAN_ACT_LRELU) go(integral_constant<int, GAN_ACT_LRELU>{}, integral_constant<bool, true>{});
+      else go(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, true>{});
+    } else {
+      if (act == GAN_ACT_RELU) go(integral_constant<int, GAN_ACT_RELU>{}, integral_constant<bool, false>{});
+      else if (act == GAN_ACT_LRELU) go(integral_constant<int, GAN_ACT_LRELU>{}, integral_constant<bool, false>{});
+      else go(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, false>{});
+    })
   if (bias_grad && !bias_part) {
     float* part = ws2 + (int64_t)BC * 2;
     const int nparts = x->B * nblk;
@@ -615,8 +802,9 @@ extern "C" int gan_fold_add(const gan_view* a, const gan_view* b, int fold, cons
   const int HW = out->H * out->W;
   const int nblk = nblocks_for(HW, lanes_of(out));
   DView va = a ? to_dview(a) : null_dview(), vb = to_dview(b), vo = to_dview(out);
-  GAN_DISPATCH_DTYPE(out->dtype, hipLaunchKernelGGL((fold_add_kernel<T>), dim3(nblk, out->B), dim3(NTHR), 0, (hipStream_t)stream, va, a ? 1 : 0,
-                                                    vb, fold, null_dview(), GAN_ACT_NONE, vo, nblk);)
+  GAN_DISPATCH_NORM(out->dtype,
+    if (fold) hipLaunchKernelGGL((fold_add_kernel<T, U, true>), dim3(nblk, out->B), dim3(NTHR), 0, (hipStream_t)stream, va, a ? 1 : 0, vb, null_dview(), GAN_ACT_NONE, vo, nblk);
+    else hipLaunchKernelGGL((fold_add_kernel<T, U, false>), dim3(nblk, out->B), dim3(NTHR), 0, (hipStream_t)stream, va, a ? 1 : 0, vb, null_dview(), GAN_ACT_NONE, vo, nblk);)
   GAN_LAUNCH_CHECK();
   return 0;
 }
@@ -630,8 +818,9 @@ extern "C" int gan_act_bwd(const gan_view* y, int act, const gan_view* g, int fo
   const int HW = dx->H * dx->W;
   const int nblk = nblocks_for(HW, lanes_of(dx));
   DView vy = to_dview(y), vg = to_dview(g), v2 = g2 ? to_dview(g2) : null_dview(), vd = to_dview(dx);
-  GAN_DISPATCH_DTYPE(dx->dtype, hipLaunchKernelGGL((fold_add_kernel<T>), dim3(nblk, dx->B), dim3(NTHR), 0, (hipStream_t)stream, v2, g2 ? 1 : 0,
-                                                   vg, fold, vy, act, vd, nblk);)
+  GAN_DISPATCH_NORM(dx->dtype,
+    if (fold) hipLaunchKernelGGL((fold_add_kernel<T, U, true>), dim3(nblk, dx->B), dim3(NTHR), 0, (hipStream_t)stream, v2, g2 ? 1 : 0, vg, vy, act, vd, nblk);
+    else hipLaunchKernelGGL((fold_add_kernel<T, U, false>), dim3(nblk, dx->B), dim3(NTHR), 0, (hipStream_t)stream, v2, g2 ? 1 : 0, vg, vy, act, vd, nblk);)
   GAN_LAUNCH_CHECK();
   return 0;
 }

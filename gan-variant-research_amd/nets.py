@@ -146,11 +146,21 @@ class GPass:
 
         def norm(i, raw, stats, act, residual=None, out=None, conv=None):
             out = self.acts[i] if out is None else out
+            halo = self.halo_mode(i) if out is self.acts[i] else net.pad_mode
+            ws = net.in_ws(self.B, raw.C)
+            fused = not os.environ.get("GAN_NO_FUSED_FINALIZE")
             if conv is not None and conv.stats_parts:     # the convolution's epilogue already wrote per-tile (sum, sum of squares)
-                prog.add(ops.in_stats_from_parts(net.in_ws(self.B, raw.C), conv.stats_parts, self.B, raw.C, raw.H * raw.W, IN_EPS, stats))
+                if fused and conv.stats_parts <= 16:          # few tiles: the apply pass adds them up itself (no statistics launch at all)
+                    prog.add(ops.in_apply_parts(raw, ws, conv.stats_parts, IN_EPS, stats, act, residual, out, halo))
+                    return
+                prog.add(ops.in_stats_from_parts(ws, conv.stats_parts, self.B, raw.C, raw.H * raw.W, IN_EPS, stats))
+            elif fused:
+                prog.add(ops.in_partial(raw, ws))
+                prog.add(ops.in_apply_parts(raw, ws, ops.in_partial_count(raw), IN_EPS, stats, act, residual, out, halo))
+                return
             else:
-                prog.add(ops.in_stats(raw, IN_EPS, stats, net.in_ws(self.B, raw.C)))
-            prog.add(ops.in_apply(raw, stats, act, residual, out, self.halo_mode(i) if out is self.acts[i] else net.pad_mode))
+                prog.add(ops.in_stats(raw, IN_EPS, stats, ws))
+            prog.add(ops.in_apply(raw, stats, act, residual, out, halo))
 
         prog.add(net.c_init.fwd(self.x0, self.raw[0], stats_ws=net.in_ws(self.B, self.raw[0].C)))
         norm(0, self.raw[0], self.stats[0], ACT_RELU, conv=net.c_init)

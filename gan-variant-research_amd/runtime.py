@@ -376,6 +376,23 @@ class HipOps:
         return self._hbm(self._call("gan_in_apply", self._v(x), self._p(stats), act, self._v(residual), self._v(y), halo_mode, self._s()),
                          x, 2 + (residual is not None))
 
+    def in_partial_count(self, x: View) -> int:
+        """Statistics partials per image gan_in_partial writes for x (<= 16: gan_in_apply_parts sums them itself)."""
+        n = int(self.lib.gan_in_partial_count(self._v(x)))
+        if n < 1:
+            raise _lib.GanError(self.lib.gan_last_error().decode())
+        return n
+
+    def in_partial(self, x: View, parts) -> Op:
+        assert parts.dtype == torch.float32 and parts.numel() >= x.B * self.in_partial_count(x) * x.C * 2
+        return self._call("gan_in_partial", self._v(x), self._p(parts), self._s())
+
+    def in_apply_parts(self, x: View, parts, nparts, eps, stats, act, residual: Optional[View], y: View, halo_mode) -> Op:
+        """InstanceNorm apply with the statistics summed from `nparts` (<= 16) partial pairs per image inside the pass (no finalize launch)."""
+        assert 1 <= nparts <= 16 and parts.numel() >= x.B * nparts * x.C * 2 and stats.numel() >= x.B * x.C * 2
+        return self._hbm(self._call("gan_in_apply_parts", self._v(x), self._p(parts), nparts, C.c_float(eps), self._p(stats), act, self._v(residual),
+                                    self._v(y), halo_mode, self._s()), x, 2 + (residual is not None))
+
     def in_bwd(self, x: View, stats, act, gy: View, fold, g2: Optional[View], dx: View, ws) -> Op:
         return self._hbm(self._call("gan_in_bwd", self._v(x), self._p(stats), act, self._v(gy), int(fold), self._v(g2), self._v(dx), self._p(ws), self._s()),
                          x, 3 + (g2 is not None))

@@ -145,6 +145,15 @@ int gan_in_stats_from_parts(const float* parts, int nparts, int B, int C, int HW
 int gan_in_finalize(float* stats, int BC, int HW, float eps, void* stream);
 int gan_in_apply(const gan_view* x, const float* stats, int act, const gan_view* residual, const gan_view* y,
                  int halo_mode, void* stream);
+/* The same pass with the statistics taken from per-chunk partial sums, parts = fp32 [B][nparts][C][2] (sum, sum of squares),
+ * 1 <= nparts <= 16: each block adds the partials of its image up itself (fp64, fixed order), so no separate statistics launch sits
+ * between the producing convolution and this pass; (mean, rstd) are also written to `stats` for the backward pass.  The partials come
+ * from a convolution epilogue (gan_conv_desc.stats with gan_conv_stats_parts(desc) <= 16) or from gan_in_partial, which writes
+ * gan_in_partial_count(x) of them per image. */
+int gan_in_partial_count(const gan_view* x);
+int gan_in_partial(const gan_view* x, float* parts, void* stream);
+int gan_in_apply_parts(const gan_view* x, const float* parts, int nparts, float eps, float* stats, int act, const gan_view* residual,
+                       const gan_view* y, int halo_mode, void* stream);
 /* backward: g = (fold of `gy` over its reflect halo if fold) [+ g2], masked by act'(xhat) (relu / lrelu);
  * dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) written to the interior of `dx` (halo untouched).
  * ws: fp32 >= B*96*C*2 + B*C*2 floats (gan_in_stats: B*96*C*2). */

@@ -125,6 +125,26 @@ class EmuOps:
             return 1 if (c.Cin == 8 and c.Nst == 64 and c.act == ACT_NONE) else 0
         return 1 if (self.conv_patch_ok(c) and c.act == ACT_NONE and c.mask is None and (c.out_sy, c.out_sx) == (1, 1)) else 0
 
+    def in_partial_count(self, x):
+        """Statement of gan_in_partial_count; the emulator writes one partial per image."""
+        return 1
+
+    def in_partial(self, x, parts):
+        def op():
+            v = x.nhwc().double()
+            parts[:x.B * x.C * 2].view(x.B, 1, x.C, 2).copy_(torch.stack([v.sum((1, 2)), (v * v).sum((1, 2))], -1).unsqueeze(1).float())
+        return op
+
+    def in_apply_parts(self, x, parts, nparts, eps, stats, act, residual, y, halo_mode):
+        """Statement of gan_in_apply_parts: gan_in_stats_from_parts followed by gan_in_apply."""
+        a = self.in_stats_from_parts(parts, nparts, x.B, x.C, x.H * x.W, eps, stats)
+        b = self.in_apply(x, stats, act, residual, y, halo_mode)
+
+        def op():
+            a()
+            b()
+        return op
+
     def in_stats_from_parts(self, parts, nparts, B, Cc, HW, eps, stats):
         def op():
             p = parts[:B * nparts * Cc * 2].view(B, nparts, Cc, 2).double().sum(1)

@@ -112,6 +112,16 @@ def test_instance_norm_twins(shape, dtype):
                [tw.g.ops.in_stats(xg, 1e-5, sg, wg), tw.g.ops.in_apply(xg, sg, act, rg, yg, mode)])
         tw.tensors.pop()  # workspace contents are a kernel detail
         tw.check(*TOL[dtype])
+        # the same forward with the statistics summed inside the apply pass from <= 16 partials per image (no finalize launch)
+        y2c, y2g = tw.view(B, H, W, C, halo, rand=False)
+        s2c, s2g = tw.f32(torch.zeros(B * C * 2))
+        npc, npg = tw.c.ops.in_partial_count(xc), tw.g.ops.in_partial_count(xg)
+        assert 1 <= npg <= 16
+        pc, pg = torch.zeros(B * npc * C * 2), torch.zeros(B * npg * C * 2, device=DEV)
+        tw.run([tw.c.ops.in_partial(xc, pc), tw.c.ops.in_apply_parts(xc, pc, npc, 1e-5, s2c, act, rc, y2c, mode)],
+               [tw.g.ops.in_partial(xg, pg), tw.g.ops.in_apply_parts(xg, pg, npg, 1e-5, s2g, act, rg, y2g, mode)])
+        tw.check(*TOL[dtype])
+        np.testing.assert_allclose(s2g.cpu().numpy(), sg.cpu().numpy(), rtol=1e-5, atol=1e-6)      # same (mean, rstd) as gan_in_stats
         # backward: folded padded-domain gradient + second addend
         gc, gg = tw.view(B, H, W, C, halo, scale=0.5)
         g2c, g2g = tw.view(B, H, W, C, 0, scale=0.5)
@@ -434,7 +444,8 @@ def test_two_gpu_ranks_equal_one_rank(tmp_path):
 def test_inference_chain_vs_oracle(tmp_path):
     """SURVEY §8f-2 on the GPU (generate_folder.py:125-205, 183-185): a reference-layout checkpoint whose `ema_G.shadow` differs from
     `generator` -> inference.load_generator (EMA preferred) -> stylize on HIP must equal the oracle's generator_forward of the EMA weights
-    -> clamp -> *0.5+0.5 -> *255 -> round within +-1 LSB (fp32 operands; bf16 within +-3)."""
+    -> clamp -> *0.5+0.5 -> *255 -> round within +-1 LSB (fp32 operands); bf16 operands within +-6 LSB = the 5e-2 image tolerance of the
+    bf16 step test on the 127.5-per-unit scale."""
     from gan_variant_research_amd import cut as C, inference as I
     from oracle import cut_ref
     C.set_seed(5)
@@ -446,7 +457,7 @@ def test_inference_chain_vs_oracle(tmp_path):
     x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(8)) * 2 - 1
     want = cut_ref.generator_forward(shadow, x).detach()
     want = (want.clamp(-1, 1) * 0.5 + 0.5).mul(255).round()
-    for bf16, lsb in ((False, 1), (True, 3)):
+    for bf16, lsb in ((False, 1), (True, 6)):
         G2 = I.load_generator(str(ck), device=DEV, bf16=bf16)
         for k, v in G2.state_dict().items():
             assert torch.equal(v.cpu(), shadow[k]), k
