@@ -277,46 +277,108 @@ __device__ __forceinline__ void row_lane_sum(const LanesT& L, float* sh, float* 
       for (int e = 0; e < N; ++e) v[e] += sh[(r * L.CL + L.cl) * N + e];
 }
 
+// element pairs (2j, 2j+1) of a raw chunk, read and written in place: the passes below walk a chunk pair by pair so that only the
+// pair's coefficients and two temporaries are live beside the UNR raw chunks
+template <typename T> struct Pairs;
+template <> struct Pairs<bf16_t> {
+  static constexpr int NP = 4;
+  static __device__ __forceinline__ void get(const u32x4_t& r, int j, float& a, float& b) {
+    a = __builtin_bit_cast(float, r[j] << 16); b = __builtin_bit_cast(float, r[j] & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void set(u32x4_t& r, int j, float a, float b) { r[j] = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+};
+template <> struct Pairs<float> {
+  static constexpr int NP = 2;
+  static __device__ __forceinline__ void get(const f32x4_t& r, int j, float& a, float& b) { a = r[2 * j]; b = r[2 * j + 1]; }
+  static __device__ __forceinline__ void set(f32x4_t& r, int j, float a, float b) { r[2 * j] = a; r[2 * j + 1] = b; }
+};
+// fold_extra on a raw chunk: the pre-images are added pair by pair (fp32 adds; the sum goes back to the chunk's storage type, i.e. a
+// border pixel's folded gradient is rounded to bf16 once more in bf16 mode -- 6 % of the pixels, 2^-9 relative)
+template <typename T>
+__device__ __forceinline__ void raw_add(Raw<T>& r, const Raw<T>& t) {
+#pragma unroll
+  for (int j = 0; j < Pairs<T>::NP; ++j) {
+    float a, b, c, d;
+    Pairs<T>::get(r, j, a, b);
+    Pairs<T>::get(t, j, c, d);
+    Pairs<T>::set(r, j, a + c, b + d);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void fold_extra_raw(const DView& g, const T* gp, int y, int x, Raw<T>& r) {
+  const int py = g.y0, px = g.x0;
+  int y2 = -1, x2 = -1;
+  if (y >= 1 && y <= py) y2 = py - y;
+  else if (y >= g.H - 1 - py && y <= g.H - 2) y2 = 2 * (g.H - 1) - y + py;
+  if (x >= 1 && x <= px) x2 = px - x;
+  else if (x >= g.W - 1 - px && x <= g.W - 2) x2 = 2 * (g.W - 1) - x + px;
+  if (x2 >= 0) raw_add<T>(r, ldraw(gp + ((y + py) * g.Wp + x2) * g.C));
+  if (y2 >= 0) {
+    raw_add<T>(r, ldraw(gp + (y2 * g.Wp + x + px) * g.C));
+    if (x2 >= 0) raw_add<T>(r, ldraw(gp + (y2 * g.Wp + x2) * g.C));
+  }
+}
+// does logical pixel (y,x) of a view with halo (py,px) collect reflect pre-images (see fold_extra)?
+__device__ __forceinline__ bool fold_needed(const DView& g, int y, int x) {
+  const int py = g.y0, px = g.x0;
+  return (y >= 1 && y <= py) || (y >= g.H - 1 - py && y <= g.H - 2) || (x >= 1 && x <= px) || (x >= g.W - 1 - px && x <= g.W - 2);
+}
+
 // ws[((b*nch + ch)*C + c)*2 + {0,1}] = partial (sum g', sum g'*x) of chunk ch over its pixels, g' = act'-masked (folded) gradient and
-// x the RAW norm input: the apply pass turns the totals into mean(g') and mean(g'*xhat) = rstd * (S2 - mean * S1) / HW in fp64
+// x the RAW norm input: the apply pass turns the totals into mean(g') and mean(g'*xhat) = rstd * (S2 - mean * S1) / HW in fp64.
+// Registers: UNR raw chunk pairs + 2N accumulators; the per-channel means (activation masks) are re-read from LDS per group.
 template <typename T, int UNR, int ACT, bool FOLD>
-__global__ __launch_bounds__(NTHR) void in_bwd_partial_kernel(DView x, const float* __restrict__ stats, DView gy, int nch, float* __restrict__ ws) {
-  constexpr int N = Chunk<T>::N;
+__global__ __launch_bounds__(NTHR, 6) void in_bwd_partial_kernel(DView x, const float* __restrict__ stats, DView gy, int nch, float* __restrict__ ws) {
+  constexpr int N = Chunk<T>::N, NP = Pairs<T>::NP;
   Lanes<T> L(x.C);
   const int b = blockIdx.y, ch = blockIdx.x, HW = x.H * x.W, cofs = L.cl * N;
   const int per = (HW + nch - 1) / nch, p0 = ch * per, p1 = min(HW, p0 + per);
-  float mean[N], s1[N], s2[N];
+  __shared__ float sh[NTHR * 8];
+  float s1[N], s2[N];
 #pragma unroll
-  for (int e = 0; e < N; ++e) {
-    mean[e] = ACT == GAN_ACT_NONE ? 0.f : stats[((int64_t)b * x.C + cofs + e) * 2];
-    s1[e] = s2[e] = 0.f;
+  for (int e = 0; e < N; ++e) s1[e] = s2[e] = 0.f;
+  if (ACT != GAN_ACT_NONE) {
+    for (int c = threadIdx.x; c < x.C; c += NTHR) sh[c] = stats[((int64_t)b * x.C + c) * 2];
+    __syncthreads();
   }
+  const float* mean = sh + cofs;
   const T *xp = image_ptr<T>(x, b, cofs), *gp = image_ptr<T>(gy, b, cofs);
   int yy, xx; pixel_yx(p0 + L.rl, x.W, yy, xx);
   Off32 ox(x, yy, xx, L.RL, x.W), og(gy, yy, xx, L.RL, x.W);
   for (int p = p0 + L.rl; p < p1; p += UNR * L.RL) {
     Raw<T> xr[UNR], gr[UNR];
-    int ys[UNR], xs[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      if (FOLD) { ys[u] = yy; xs[u] = xx; }
-      if (p + u * L.RL < p1) { xr[u] = ldraw(xp + ox.o); gr[u] = ldraw(gp + og.o); }
-      const int wr = pixel_step(L.RL, x.W, yy, xx);
-      ox.advance(wr); og.advance(wr);
-    }
+    unsigned fmask = 0;              // bit u: pixel u collects reflect pre-images (border pixels only)
+    asm volatile("" ::: "memory");   // the LDS reads below stay inside the loop (hoisted, they would cost N registers)
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       if (p + u * L.RL < p1) {
-        float g[N], xv[N];
-        cvtraw<T>(gr[u], g);
-        if (FOLD) fold_extra<T>(gy, gp, ys[u], xs[u], g);
-        cvtraw<T>(xr[u], xv);
+        xr[u] = ldraw(xp + ox.o); gr[u] = ldraw(gp + og.o);
+        if (FOLD && fold_needed(gy, yy, xx)) fmask |= 1u << u;
+      } else { xr[u] = Raw<T>{}; gr[u] = Raw<T>{}; }          // zero gradient: contributes nothing
+      const int wr = pixel_step(L.RL, x.W, yy, xx);
+      ox.advance(wr); og.advance(wr);
+    }
+    if (FOLD && fmask) {
 #pragma unroll
-        for (int e = 0; e < N; ++e) { const float gm = act_mask<ACT>(g[e], xv[e], mean[e]); s1[e] += gm; s2[e] += gm * xv[e]; }
+      for (int u = 0; u < UNR; ++u)
+        if ((fmask >> u) & 1) {    // border pixel (rare): add the pre-images to the raw chunk
+          const int pu = p + u * L.RL, fy = pu / x.W, fx = pu - fy * x.W;
+          fold_extra_raw<T>(gy, gp, fy, fx, gr[u]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const float ma = ACT == GAN_ACT_NONE ? 0.f : mean[2 * j], mb = ACT == GAN_ACT_NONE ? 0.f : mean[2 * j + 1];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        float xa, xb, ga, gb;
+        Pairs<T>::get(xr[u], j, xa, xb);
+        Pairs<T>::get(gr[u], j, ga, gb);
+        ga = act_mask<ACT>(ga, xa, ma); gb = act_mask<ACT>(gb, xb, mb);
+        s1[2 * j] += ga; s2[2 * j] += ga * xa; s1[2 * j + 1] += gb; s2[2 * j + 1] += gb * xb;
       }
     }
   }
-  __shared__ float sh[NTHR * 8];
   row_lane_sum<N>(L, sh, s1);
   row_lane_sum<N>(L, sh, s2);
   if (L.rl == 0) {
@@ -326,65 +388,79 @@ __global__ __launch_bounds__(NTHR) void in_bwd_partial_kernel(DView x, const flo
   }
 }
 // dx = rstd * (g' - mean(g') - xhat * mean(g'*xhat)) = g' * A + x * Bc + Cc with per-channel A = rstd, Bc = -rstd^2 m2, Cc = -rstd m1 +
-// rstd^2 m2 mean, computed once per block (fp64) from the nch partials of in_bwd_partial_kernel.
+// rstd^2 m2 mean, computed once per block (fp64) from the nch partials of in_bwd_partial_kernel and kept in LDS as (mean, A, Bc, Cc):
+// a group of UNR pixels is finished pair of channels by pair of channels, so only two coefficient quads are live at a time.
 // bias_part (optional): this block's row of the bias-gradient partials.  The gradient of a bias in front of a non-affine InstanceNorm is
 // the column sum of dx, which is IDENTICALLY zero: sum_p dx = A S1 + Bc HW mean + HW Cc = rstd S1 - HW rstd (S1 / HW).  The reference's
 // autograd value is the rounding noise of that sum (|g| ~ 1e-9); here the sum is evaluated in closed form from the
 // same totals (fp64) by the image's first block -- the other blocks' rows are zero -- instead of being re-accumulated per element.
 template <typename T, int UNR, int ACT, bool FOLD>
-__global__ __launch_bounds__(NTHR) void in_bwd_apply_kernel(DView x, const float* __restrict__ stats, DView gy, const float* __restrict__ ws, int nch,
+__global__ __launch_bounds__(NTHR, 6) void in_bwd_apply_kernel(DView x, const float* __restrict__ stats, DView gy, const float* __restrict__ ws, int nch,
                                                            DView dx, int nblk, float* __restrict__ bias_part) {
-  constexpr int N = Chunk<T>::N;
+  constexpr int N = Chunk<T>::N, NP = Pairs<T>::NP;
   Lanes<T> L(x.C);
   const int b = blockIdx.y, HW = x.H * x.W, cofs = L.cl * N;
   const int per = (HW + nblk - 1) / nblk, p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
   __shared__ float sh[NTHR * 8];
-  float mean[N], A[N], Bc[N], Cc[N];
-  {
-    f32x4_t* sh4 = reinterpret_cast<f32x4_t*>(sh);        // [C] x (mean, A, Bc, Cc); C <= SUMS_MAXC = NTHR * 8 / 4
-    for (int c = threadIdx.x; c < x.C; c += NTHR) {
-      const float2* pp = reinterpret_cast<const float2*>(ws + ((int64_t)b * nch * x.C + c) * 2);
-      double S1 = 0.0, S2 = 0.0;
+  f32x4_t* sh4 = reinterpret_cast<f32x4_t*>(sh);        // [C] x (mean, A, Bc, Cc); C <= NTHR * 8 / 4
+  for (int c = threadIdx.x; c < x.C; c += NTHR) {
+    const float2* pp = reinterpret_cast<const float2*>(ws + ((int64_t)b * nch * x.C + c) * 2);
+    double S1 = 0.0, S2 = 0.0;
 #pragma unroll 8
-      for (int k = 0; k < nch; ++k) { const float2 t = pp[(int64_t)k * x.C]; S1 += t.x; S2 += t.y; }
-      const double mu = stats[((int64_t)b * x.C + c) * 2], rs = stats[((int64_t)b * x.C + c) * 2 + 1];
-      const double m1 = S1 / HW, m2 = rs * (S2 - mu * S1) / HW;
-      const double bcd = -rs * rs * m2, ccd = -rs * m1 + rs * rs * m2 * mu;
-      const f32x4_t r = {(float)mu, (float)rs, (float)bcd, (float)ccd};
-      sh4[c] = r;
-      if (bias_part) bias_part[(int64_t)(b * nblk + blockIdx.x) * x.C + c] = blockIdx.x == 0 ? (float)(rs * S1 + bcd * (HW * mu) + HW * ccd) : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < N; ++e) { const f32x4_t r = sh4[cofs + e]; mean[e] = r[0]; A[e] = r[1]; Bc[e] = r[2]; Cc[e] = r[3]; }
+    for (int k = 0; k < nch; ++k) { const float2 t = pp[(int64_t)k * x.C]; S1 += t.x; S2 += t.y; }
+    const double mu = stats[((int64_t)b * x.C + c) * 2], rs = stats[((int64_t)b * x.C + c) * 2 + 1];
+    const double m1 = S1 / HW, m2 = rs * (S2 - mu * S1) / HW;
+    const double bcd = -rs * rs * m2, ccd = -rs * m1 + rs * rs * m2 * mu;
+    const f32x4_t r = {(float)mu, (float)rs, (float)bcd, (float)ccd};
+    sh4[c] = r;
+    if (bias_part) bias_part[(int64_t)(b * nblk + blockIdx.x) * x.C + c] = blockIdx.x == 0 ? (float)(rs * S1 + bcd * (HW * mu) + HW * ccd) : 0.f;
   }
+  __syncthreads();
+  const f32x4_t* cf = sh4 + cofs;
   const T *xp = image_ptr<T>(x, b, cofs), *gp = image_ptr<T>(gy, b, cofs);
   T* dp = const_cast<T*>(image_ptr<T>(dx, b, cofs));
   int yy, xx; pixel_yx(p0 + L.rl, x.W, yy, xx);
   Off32 ox(x, yy, xx, L.RL, x.W), og(gy, yy, xx, L.RL, x.W), od(dx, yy, xx, L.RL, x.W);
   for (int p = p0 + L.rl; p < p1; p += UNR * L.RL) {
     Raw<T> xr[UNR], gr[UNR];
-    int ys[UNR], xs[UNR], ods[UNR];
+    int ods[UNR];
+    unsigned fmask = 0, live = 0;    // bit u: pixel u collects reflect pre-images (border pixels only) / lies inside this block's range
+    asm volatile("" ::: "memory");   // the coefficient reads stay inside the loop (hoisted, they would cost 4N registers)
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      if (FOLD) { ys[u] = yy; xs[u] = xx; }
       ods[u] = od.o;
-      if (p + u * L.RL < p1) { xr[u] = ldraw(xp + ox.o); gr[u] = ldraw(gp + og.o); }
+      if (p + u * L.RL < p1) {
+        xr[u] = ldraw(xp + ox.o); gr[u] = ldraw(gp + og.o);
+        live |= 1u << u;
+        if (FOLD && fold_needed(gy, yy, xx)) fmask |= 1u << u;
+      }
       const int wr = pixel_step(L.RL, x.W, yy, xx);
       ox.advance(wr); og.advance(wr); od.advance(wr);
     }
+    if (FOLD && fmask) {
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      if (p + u * L.RL < p1) {
-        float g[N], xv[N];
-        cvtraw<T>(gr[u], g);
-        if (FOLD) fold_extra<T>(gy, gp, ys[u], xs[u], g);
-        cvtraw<T>(xr[u], xv);
+      for (int u = 0; u < UNR; ++u)
+        if ((fmask >> u) & 1) {    // border pixel (rare): add the pre-images to the raw chunk
+          const int pu = p + u * L.RL, fy = pu / x.W, fx = pu - fy * x.W;
+          fold_extra_raw<T>(gy, gp, fy, fx, gr[u]);
+        }
+    }
 #pragma unroll
-        for (int e = 0; e < N; ++e) g[e] = act_mask<ACT>(g[e], xv[e], mean[e]) * A[e] + (xv[e] * Bc[e] + Cc[e]);
-        Chunk<T>::store(dp + ods[u], g);
+    for (int j = 0; j < NP; ++j) {
+      const f32x4_t ca = cf[2 * j], cb = cf[2 * j + 1];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        float xa, xb, ga, gb;
+        Pairs<T>::get(xr[u], j, xa, xb);
+        Pairs<T>::get(gr[u], j, ga, gb);
+        ga = act_mask<ACT>(ga, xa, ca[0]) * ca[1] + (xa * ca[2] + ca[3]);
+        gb = act_mask<ACT>(gb, xb, cb[0]) * cb[1] + (xb * cb[2] + cb[3]);
+        Pairs<T>::set(gr[u], j, ga, gb);
       }
     }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+      if ((live >> u) & 1) *reinterpret_cast<Raw<T>*>(dp + ods[u]) = gr[u];
   }
 }
 // out[seg][c] (+)= sum over this segment's blocks of part[blk][c]; gridDim.y segments (two-level reduction: many partials,
@@ -436,7 +512,7 @@ __global__ __launch_bounds__(1024) void bias_finalize_batch_kernel(const gan_bia
 
 // out = a + fold(b)   /   dx = (fold(g) + g2) * act'(y)
 template <typename T, int UNR, bool FOLD>
-__global__ __launch_bounds__(NTHR) void fold_add_kernel(DView a, int has_a, DView g, DView y, int act, DView out, int nblk) {
+__global__ __launch_bounds__(NTHR, 6) void fold_add_kernel(DView a, int has_a, DView g, DView y, int act, DView out, int nblk) {
   constexpr int N = Chunk<T>::N;
   Lanes<T> L(out.C);
   const int b = blockIdx.y, HW = out.H * out.W, cofs = L.cl * N;
@@ -593,19 +669,19 @@ int fold_ok(const gan_view* g, int fold) {
 }  // namespace
 
 // pixels in flight per thread of the streaming kernels: 2 for the backward family (fits beside a resident weight-gradient block: <= 80
-// registers), 4 for the forward passes, which run alone.  GAN_NORM_UNR / GAN_NORM_UNR_FWD = 2 or 4 override (tuning aid, read once).
+// registers), 4 for the forward passes, which run alone.  GAN_NORM_UNR / GAN_NORM_UNR_FWD = 2, 3 or 4 override (tuning aid, read once).
 static int norm_unroll(bool fwd) {
   static int u[2] = {0, 0};
-  if (!u[fwd]) { const char* e = getenv(fwd ? "GAN_NORM_UNR_FWD" : "GAN_NORM_UNR"); const int v = e ? atoi(e) : (fwd ? 4 : 2); u[fwd] = v == 2 || v == 4 ? v : (fwd ? 4 : 2); }
+  if (!u[fwd]) { const char* e = getenv(fwd ? "GAN_NORM_UNR_FWD" : "GAN_NORM_UNR"); const int v = e ? atoi(e) : (fwd ? 4 : 2); u[fwd] = v >= 2 && v <= 4 ? v : (fwd ? 4 : 2); }
   return u[fwd];
 }
 #define GAN_DISPATCH_NORM_U(dt, fwd, ...)                                            \
   {                                                                                  \
     const int unr__ = norm_unroll(fwd);                                              \
     if ((dt) == GAN_F32) { typedef float T;                                          \
-      if (unr__ == 2) { constexpr int U = 2; __VA_ARGS__ } else { constexpr int U = 4; __VA_ARGS__ } } \
+      if (unr__ == 2) { constexpr int U = 2; __VA_ARGS__ } else if (unr__ == 3) { constexpr int U = 3; __VA_ARGS__ } else { constexpr int U = 4; __VA_ARGS__ } } \
     else { typedef bf16_t T;                                                         \
-      if (unr__ == 2) { constexpr int U = 2; __VA_ARGS__ } else { constexpr int U = 4; __VA_ARGS__ } } \
+      if (unr__ == 2) { constexpr int U = 2; __VA_ARGS__ } else if (unr__ == 3) { constexpr int U = 3; __VA_ARGS__ } else { constexpr int U = 4; __VA_ARGS__ } } \
   }
 #define GAN_DISPATCH_NORM(dt, ...) GAN_DISPATCH_NORM_U(dt, false, __VA_ARGS__)
 #define GAN_DISPATCH_NORM_FWD(dt, ...) GAN_DISPATCH_NORM_U(dt, true, __VA_ARGS__)
