@@ -119,6 +119,8 @@ class CycleGANTrainer:
         amp = cfg["training"].get("amp", True) if amp is None else amp
         self.dtype = BF16 if amp else F32
         self.ops = ops if ops is not None else HipOps(self.device)
+        if hasattr(self.ops, "bind"):
+            self.ops.bind()
         self.ctx = Ctx(self.ops, self.device, self.dtype)
         self.world_size, self.pg = world_size, process_group
         self.gan = GANLoss(cfg["loss"]["gan"])

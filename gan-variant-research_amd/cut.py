@@ -338,6 +338,8 @@ class CutTrainer:
         amp = config.get("amp", True) if amp is None else amp
         self.amp = AMPContext(amp)
         self.ops = ops if ops is not None else HipOps(self.device)
+        if hasattr(self.ops, "bind"):
+            self.ops.bind()                 # one stream for this trainer's launches and its torch-side copies / events, from now on
         if hasattr(self.ops, "bind_queues"):
             self.ops.bind_queues()          # no-op cost; matters when this runs before torch.distributed creates RCCL's streams
         self.ctx = Ctx(self.ops, self.device, self.amp.dtype)

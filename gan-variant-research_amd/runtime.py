@@ -169,12 +169,7 @@ class HipOps:
     def __init__(self, device: torch.device, stream: Optional[int] = None, torch_stream=None):
         self.lib = _lib.load()
         self.device = device
-        if stream is None and self.device.type == "cuda":
-            # bind to the stream that is current NOW: launches (raw handle baked into the prebuilt calls) and the torch-side events,
-            # copies and collectives (_ts) must always meet on one stream, whatever is current when a program is replayed
-            torch_stream = torch.cuda.current_stream(self.device)
-            stream = torch_stream.cuda_stream
-        self.stream = stream
+        self.stream = stream  # None: torch's current stream at op-construction time (the module API builds graph slots that way); see bind()
         self.torch_stream = torch_stream   # the torch.cuda.Stream behind `stream` (needed for event record / wait)
         self._keep = []       # ctypes structs referenced by prebuilt calls
         self._side = None
@@ -209,6 +204,15 @@ class HipOps:
             with torch.cuda.stream(h._ts()):
                 torch.zeros(64, device=self.device).add_(1.0)
         torch.cuda.synchronize(self.device)
+
+    def bind(self):
+        """Binds an op layer created without a stream to the stream that is current NOW, for good: launches (raw handle baked into the
+        prebuilt calls) and the torch-side events, copies and collectives (_ts) of a trainer then always meet on one stream,
+        whatever is current when its programs are built or replayed."""
+        if self.stream is None and self.device.type == "cuda":
+            self.torch_stream = torch.cuda.current_stream(self.device)
+            self.stream = self.torch_stream.cuda_stream
+        return self
 
     def _ts(self):
         return self.torch_stream if self.torch_stream is not None else torch.cuda.current_stream(self.device)

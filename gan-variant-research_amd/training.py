@@ -122,6 +122,37 @@ class HipAdam(torch.optim.Optimizer):
                     self._state(p)
 
 
+_FUSED_PLANS = {}
+
+
+def fused_adam_launch(params, grads, m, v, ema, steps, lr, b1, b2, eps, max_norm, grad_scale, ema_decay):
+    """Body of torch.ops.mi355x_gan.fused_clip_adam_ema_: clip_grad_norm_(max_norm; 0 = off) on grads * grad_scale, one Adam
+    step of every tensor (per-tensor step counters `steps`, int32 [n], incremented on the device) and, if `ema` is non-empty,
+    shadow <- decay * shadow + (1 - decay) * p, in three launches regardless of the tensor count.  Returns the total gradient norm."""
+    n = len(params)
+    assert n and len(grads) == n and len(m) == n and len(v) == n and len(ema) in (0, n) and steps.dtype == torch.int32 and steps.numel() == n
+    key = tuple(t.data_ptr() for grp in (params, grads, m, v, ema) for t in grp) + (steps.data_ptr(),)
+    pl = _FUSED_PLANS.get(key)
+    if pl is None:
+        dev = params[0].device
+        ctx = AG._new_ctx(dev, F32)
+        ents, ct, co = [], [], []
+        for i in range(n):
+            for t in (params[i], grads[i], m[i], v[i]) + ((ema[i],) if ema else ()):
+                assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == params[i].numel()
+            ents.append({"p": params[i].view(-1), "g": grads[i].view(-1), "m": m[i].view(-1), "v": v[i].view(-1),
+                         "ema": ema[i].view(-1) if ema else None, "step": steps[i:i + 1]})
+            for off in range(0, params[i].numel(), ADAM_CHUNK):
+                ct.append(i); co.append(off)
+        pl = _FUSED_PLANS[key] = {"ctx": ctx, "norm": torch.zeros(2, dtype=torch.float32, device=dev), "table": ctx.ops.make_adam_table(ents),
+                                  "ct": torch.tensor(ct, dtype=torch.int32, device=dev), "co": torch.tensor(co, dtype=torch.int64, device=dev),
+                                  "ws": torch.zeros(len(ct) + 16, dtype=torch.float32, device=dev), "keep": (params, grads, m, v, ema, steps)}
+    pl["ctx"].ops.adam_step(pl["table"], n, pl["ct"], pl["co"], len(pl["ct"]), lr, b1, b2, eps, max_norm, grad_scale, ema_decay if ema else 0.0,
+                            pl["norm"], pl["ws"])()
+    AG.notify_weights_changed()
+    return pl["norm"][:1].clone()
+
+
 def get_optimizer(model, opt_config: dict):
     """sched_optim.py:5-27 (Adam only on this path; the reference's default type is also 'adam')."""
     kind = opt_config.get("type", "adam").lower()

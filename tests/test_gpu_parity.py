@@ -441,6 +441,17 @@ def test_two_gpu_ranks_equal_one_rank(tmp_path):
         np.testing.assert_allclose(0.5 * (res[0]["losses"][k] + res[1]["losses"][k]), ref_losses[k], rtol=1e-3, atol=1e-4, err_msg=k)
 
 
+def test_ops_library_hip(monkeypatch):
+    """torch.ops.mi355x_gan.* on the kernels: the generator and discriminator assembled layer by layer from the op-level drop-in modules
+    reproduce the reference's own outputs (golden) and the oracle's gradients; the fused clip+Adam+EMA op matches torch.optim.Adam."""
+    from gan_variant_research_amd import ops_library as L, training as T
+    from tests.test_ops_library import fused_adam_case, layerwise_cases
+    monkeypatch.setattr(L, "_PLANS", {})
+    monkeypatch.setattr(T, "_FUSED_PLANS", {})
+    layerwise_cases(torch.device(DEV), 1e-3)
+    fused_adam_case(torch.device(DEV))
+
+
 def test_inference_chain_vs_oracle(tmp_path):
     """SURVEY §8f-2 on the GPU (generate_folder.py:125-205, 183-185): a reference-layout checkpoint whose `ema_G.shadow` differs from
     `generator` -> inference.load_generator (EMA preferred) -> stylize on HIP must equal the oracle's generator_forward of the EMA weights
