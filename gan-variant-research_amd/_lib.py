@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmi355x_gan.so")
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2     # FP8: OCP e4m3 operand copies of the bottleneck convolutions (BASELINE.json configs[4])
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 HALO_NONE, HALO_ZERO, HALO_REFLECT = 0, 1, 2
 
@@ -29,7 +29,7 @@ class GanConvDesc(C.Structure):
                 ("tapoff", vp), ("w", vp), ("bias", vp), ("out", vp),
                 ("out_Hp", i32), ("out_Wp", i32), ("out_C", i32), ("out_y0", i32), ("out_x0", i32), ("out_sy", i32), ("out_sx", i32),
                 ("act", i32), ("mask", vp), ("mask_Hp", i32), ("mask_Wp", i32), ("mask_y0", i32), ("mask_x0", i32), ("stats", vp), ("max_tapoff", i32), ("w_layout", i32),
-                ("win_ty0", i32), ("win_tx0", i32), ("tile_rows", i32), ("_pad", i32)]
+                ("win_ty0", i32), ("win_tx0", i32), ("tile_rows", i32), ("_pad", i32), ("w_scale", vp), ("in_scale", vp)]
 
 
 class GanWgradDesc(C.Structure):
@@ -46,7 +46,7 @@ class GanAdamTensor(C.Structure):
 
 class GanPackDesc(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("khw", vp), ("dtype", i32), ("Nw", i32), ("ntaps", i32), ("Cin", i32), ("N_real", i32), ("C_real", i32),
-                ("swap", i32), ("I2", i32), ("KK", i32), ("layout", i32), ("first_block", i32), ("nblocks", i32)]
+                ("swap", i32), ("I2", i32), ("KK", i32), ("layout", i32), ("first_block", i32), ("nblocks", i32), ("scale", vp)]
 
 
 class GanBiasPartDesc(C.Structure):
@@ -77,6 +77,9 @@ PROTOTYPES = {
     "gan_in_stats_from_parts": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp]),
     "gan_pack_weight": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "gan_pack_weight_batch": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+    "gan_weight_scale_batch": (C.c_int, [vp, C.c_int, vp]),
+    "gan_quantize_fp8": (C.c_int, [PV, PV, vp, vp, vp]),
+    "gan_in_bwd_amax": (C.c_int, [PV, vp, C.c_int, PV, C.c_int, PV, vp, vp, vp, vp]),
     "gan_bias_grad": (C.c_int, [PV, C.c_int, vp, C.c_int, vp, vp]),
     "gan_in_stats": (C.c_int, [PV, f32, vp, vp, vp]),
     "gan_in_finalize": (C.c_int, [vp, C.c_int, C.c_int, f32, vp]),

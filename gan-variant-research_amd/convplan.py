@@ -14,7 +14,7 @@ from typing import List, Optional, Tuple
 
 import torch
 
-from ._lib import ACT_NONE, BF16, F32
+from ._lib import ACT_NONE, BF16, F32, FP8, GanError
 from .runtime import ConvCall, Ctx, View, WgradCall, cpad
 
 
@@ -41,6 +41,8 @@ class _Pack:
         self.khw = ctx.i32([t[2] for t in taps] + [-1] * (nt - len(taps)))
         self._w = None     # row-major copy (generic kernel), allocated on first use
         self._wf = None    # fragment-major copy (range-patch kernel), allocated on first use
+        self._wf8 = None   # fragment-major e4m3 copy (range-patch kernel, fp8 operands) and its per-tensor scale max|W| / 448
+        self.scale8 = None
         self._tapoff = {}
 
     @property
@@ -55,9 +57,28 @@ class _Pack:
             self._wf = torch.zeros(self.nw * self.ntaps * self.cred, dtype=self.ctx.tdtype, device=self.ctx.device)
         return self._wf
 
+    @property
+    def wf8(self) -> torch.Tensor:
+        if self._wf8 is None:
+            self._wf8 = torch.zeros(self.nw * self.ntaps * self.cred, dtype=torch.uint8, device=self.ctx.device)
+            self.scale8 = torch.ones(1, dtype=torch.float32, device=self.ctx.device)
+        return self._wf8
+
+    def finalize8(self, c: ConvCall) -> ConvCall:
+        """fp8 operands (c.x is an e4m3 view): the range-patch kernel or nothing -- there is no other fp8 convolution."""
+        assert c.x.dtype == FP8
+        c.w, c.w_frag, c.w_scale = self.wf8, True, self.scale8
+        if not self.ctx.ops.conv_patch_ok(c):
+            raise GanError(f"fp8 convolution: B{c.B} {c.Ho}x{c.Wo} Cin{c.Cin} taps{c.ntaps} does not qualify for the range-patch kernel")
+        c.tile_rows = self.ctx.ops.conv_patch_tile_rows(c)
+        return c
+
     def pack_ops(self, master: torch.Tensor):
         """Refreshes every operand copy that some planned call uses (plan all calls BEFORE building the repack program)."""
         out = []
+        if self._wf8 is not None:
+            out.append(self.ctx.ops.pack_weight(master, self._wf8, FP8, self.nw, self.ntaps, self.cred, self.n_real, self.c_real, self.swap,
+                                                self.i2, self.kk, self.khw, 1, self.scale8))
         for buf, layout in ((self._w, 0), (self._wf, 1)):
             if buf is not None:
                 out.append(self.ctx.ops.pack_weight(master, buf, self.ctx.dtype, self.nw, self.ntaps, self.cred, self.n_real, self.c_real,
@@ -216,6 +237,38 @@ class ConvLayer:
             return [ops.conv_igemm(call)]
         assert (y.H, y.W) == (2 * x.H, 2 * x.W)
         return self._phased(self.fwd_packs, x, y, act, self.bias_k if use_bias else None, mask)
+
+    def fwd8(self, x8: View, y: View, act: int = ACT_NONE, stats_ws: Optional[torch.Tensor] = None, in_scale: Optional[torch.Tensor] = None):
+        """Forward on e4m3 operands (x8 = gan_quantize_fp8 copy of the input, unit scale unless in_scale; the weight copy is this
+        layer's fp8 pack); the result `y` is bf16.  Stride-1 convolutions on the range-patch kernel (the residual 3x3 256->256 layers)."""
+        assert not self.transposed and self.s == 1 and x8.dtype == FP8 and y.dtype == BF16 and x8.C == cpad(self.cin) and y.C == cpad(self.cout)
+        ops, k, p = self.ctx.ops, self.k, self.p
+        assert (y.H, y.W) == (x8.H + 2 * p - k + 1, x8.W + 2 * p - k + 1) and x8.halo >= p
+        pk = self.fwd_pack
+        call = pk.finalize8(ConvCall(x8.B, y.H, y.W, pk.cred, pk.ntaps, pk.nw, min(pk.nw, y.C), x8, x8.halo - p, x8.halo - p, 1, 1, pk.tapoff(x8.Wp), None,
+                                     self.bias_k, y, y.halo, y.halo, 1, 1, act, None, 0, 0, pk.max_tapoff(x8.Wp), in_scale=in_scale))
+        self.stats_parts = 0
+        if stats_ws is not None and call.Nst == y.C and not os.environ.get("GAN_NO_FUSED_STATS"):
+            n = ops.conv_stats_parts(call)
+            if 0 < n and x8.B * n * y.C * 2 <= stats_ws.numel():
+                call.stats, self.stats_parts = stats_ws, n
+        return [ops.conv_igemm(call)]
+
+    def dgrad8(self, dy8: View, dx: View, in_scale: torch.Tensor, padded_domain: bool = False):
+        """Input gradient on e4m3 operands: dy8 = per-image-scaled e4m3 copy of dY (zero halo), in_scale its scales; dx is bf16."""
+        assert not self.transposed and self.s == 1 and dy8.dtype == FP8 and dx.dtype == BF16
+        ops, k, p = self.ctx.ops, self.k, self.p
+        pk = self.dgrad_packs[0]
+        if padded_domain:
+            assert dx.halo == p and dy8.halo >= k - 1
+            gh, gw, oy, iy = dx.Hp, dx.Wp, 0, dy8.halo - (k - 1)
+        else:
+            assert dy8.halo >= k - 1 - p
+            gh, gw, oy, iy = dx.H, dx.W, dx.halo, dy8.halo - (k - 1) + p
+        call = pk.finalize8(ConvCall(dy8.B, gh, gw, pk.cred, pk.ntaps, pk.nw, min(pk.nw, dx.C), dy8, iy, iy, 1, 1, pk.tapoff(dy8.Wp), None, None, dx,
+                                     oy, oy, 1, 1, ACT_NONE, None, 0, 0, pk.max_tapoff(dy8.Wp), in_scale=in_scale))
+        call.alg_pixels = dy8.H * dy8.W
+        return [ops.conv_igemm(call)]
 
     def _pair_packs(self, packs):
         """Lazily built _PairPack per phase row (see there); None when the layer does not qualify."""

@@ -29,6 +29,13 @@ int gan_set_error(int code, const char* fmt, ...);
 __device__ __forceinline__ float bf2f(bf16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
+// OCP e4m3 (GAN_FP8): v_cvt_pk_fp8_f32 rounds to nearest even and turns out-of-range values into NaN, so operands are clamped to +-448
+__device__ __forceinline__ uint32_t f2e4m3x4(float a, float b, float c, float d) {
+  auto cl = [](float v) { return fminf(fmaxf(v, -448.f), 448.f); };
+  uint32_t r = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), 0u, false);
+  return __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), r, true);
+}
+
 // 16-byte chunk of an activation: 4 fp32 or 8 bf16, handled as floats in registers.
 template <typename T> struct Chunk;
 template <> struct Chunk<float> {

@@ -208,8 +208,9 @@ int gan_conv_win7_launch(const gan_conv_desc* d, hipStream_t s);
 
 extern "C" int gan_conv_igemm(const gan_conv_desc* d, void* stream) {
   GAN_CHECK(d, "conv: null descriptor");
-  GAN_CHECK(d->dtype == GAN_F32 || d->dtype == GAN_BF16, "conv: bad dtype %d", d->dtype);
-  const int es = d->dtype == GAN_F32 ? 4 : 2, bke = 128 / es;
+  GAN_CHECK(d->dtype == GAN_F32 || d->dtype == GAN_BF16 || d->dtype == GAN_FP8, "conv: bad dtype %d", d->dtype);
+  GAN_CHECK(d->dtype != GAN_FP8 || d->w_layout == 1, "conv: fp8 operands run on the range-patch kernel only (w_layout 1, gan_conv_patch_ok)");
+  const int es = d->dtype == GAN_F32 ? 4 : d->dtype == GAN_FP8 ? 1 : 2, bke = 128 / es;
   GAN_CHECK(d->B > 0 && d->Ho > 0 && d->Wo > 0, "conv: empty problem");
   GAN_CHECK(d->Cin >= 8 && (d->Cin & (d->Cin - 1)) == 0, "conv: Cin=%d must be a power of two >= 8", d->Cin);
   GAN_CHECK(d->ntaps > 0 && d->ntaps <= 128 && ((int64_t)d->ntaps * d->Cin) % bke == 0, "conv: ntaps*Cin=%d*%d not a multiple of %d",

@@ -38,6 +38,8 @@ struct PatchArgs {
   int Nst, act;
   int mask_Hp, mask_Wp, mask_y0, mask_x0;
   int w_bytes;
+  int tapdiv;                   // tapoff[] / tapdiv = pixel offset of a tap (the operand's REAL channel count; Cin counts 2-byte slots)
+  const float* w_scale; const float* in_scale;   // FP8: dequantisation scales (weights: one float; input: per image or NULL)
   float* stats;                 // optional per-tile InstanceNorm partials [B][MT_img][out_C][2] (sum, sum of squares), plain stores
   unsigned long long* stamps;   // diagnostic build only (GAN_PATCH_STAMPS): [block][32] s_memtime stamps of wave 0
 };
@@ -88,8 +90,16 @@ __device__ __forceinline__ TileGeo tile_geo(const PatchArgs& a, int tau) {
 // NT > 0: static schedule for exactly NT taps and an even number of 64-channel slabs -- the tap loop is unrolled, tap offsets
 // live in scalar registers, the LDS buffer index is a compile-time constant (folded into the ds_read immediate) and, where
 // registers allow (FI <= 4), the swizzled fragment addresses of all taps are computed once per tile.  NT = 0: any tap count.
-template <int BM, int WGN, int NT>
+// FP8: `in` and `w` hold e4m3 bytes, two channels per 2-byte slot of the bf16 image (Cin = real channels / 2): the kernel moves exactly
+// the bytes it moves for bf16; the two 16-byte fragments a lane reads for the two 32-slot k-steps of a tap are the low / high half of
+// its 32-byte operand of v_mfma_scale_f32_16x16x128_f8f6f4 (lane l: row l % 16, k block l / 16 -- probed with exact integer data,
+// tools/probe/fp8_mfma.hip; both operands permute the 128 channels of a k-step identically, so the product is unchanged).  Per byte
+// moved the fp8 MFMA takes the cycles of the two bf16 MFMAs it replaces: twice the FLOPs per byte, HBM and LDS traffic halved.
+typedef __attribute__((ext_vector_type(8))) int v8i_t;
+typedef __attribute__((ext_vector_type(4))) int v4i_t;
+template <int BM, int WGN, int NT, bool FP8 = false>
 __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
+  static_assert(!FP8 || NT == 0, "the fp8 path uses the generic tap loop");
   constexpr int FI = BM / (8 / WGN) / 16, FJ = BN / WGN / 16;   // fragments per wave: FI pixel groups x FJ channel groups
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   char* pbuf = lds;                       // [2][PATCHB]
@@ -97,11 +107,11 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
   float* stsh = reinterpret_cast<float*>(lds + 2 * PATCHB + 512);   // [8 waves][16*FJ channels][2]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < a.ntaps; i += NTHR) taptab[i] = a.tapoff[i] / a.Cin;   // pixel offsets
+  for (int i = tid; i < a.ntaps; i += NTHR) taptab[i] = a.tapoff[i] / a.tapdiv;   // pixel offsets
   int stoff[NT > 0 ? NT : 1];   // static schedule: pixel offset of every tap, wave-uniform
   if constexpr (NT > 0) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) stoff[t] = __builtin_amdgcn_readfirstlane(a.tapoff[t] / a.Cin);
+    for (int t = 0; t < NT; ++t) stoff[t] = __builtin_amdgcn_readfirstlane(a.tapoff[t] / a.tapdiv);
   }
   const int G = gridDim.x;
   // XCD-aware start tile: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), and the NTILES channel tiles
@@ -162,7 +172,20 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
     for (int j = 0; j < NSLICE; ++j) slab_store(0, j, tmp[j]);
   }
   u32x4_t Wa[FJ], Wb[FJ], Xa[FI], Xb[FI];   // operand fragments of the even / odd k-step of a tap
-  w_load(g.n0, kb_of(0, 0), Wa);
+  // FP8: 32-byte operands of a whole tap (both k-steps), two sets: the tap being multiplied and the next one in flight
+  v8i_t W8[2][FP8 ? FJ : 1], X8[2][FP8 ? FI : 1];
+  auto w_load8 = [&](int n0_tile, int kb, v8i_t (&f)[FP8 ? FJ : 1]) {
+    const int base = __builtin_amdgcn_readfirstlane((((n0_tile + wn_u * (16 * FJ)) >> 4) * a.KB + kb) * 1024);
+#pragma unroll
+    for (int j = 0; j < (FP8 ? FJ : 1); ++j) {
+      const u32x4_t lo = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, base + j * a.KB * 1024, 0));
+      const u32x4_t hi = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, base + j * a.KB * 1024 + 1024, 0));
+      f[j] = __builtin_shufflevector(__builtin_bit_cast(v4i_t, lo), __builtin_bit_cast(v4i_t, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+  if constexpr (FP8) w_load8(g.n0, kb_of(0, 0), W8[0]);
+  else w_load(g.n0, kb_of(0, 0), Wa);
+
   __syncthreads();   // tap table + slab 0 visible
   stamp();
 
@@ -271,6 +294,85 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
         static_slab(std::integral_constant<int, 0>{}, c);
         static_slab(std::integral_constant<int, 1>{}, c + 1);
       }
+    } else if constexpr (FP8) {
+      for (int c = 0; c < a.nchunk; ++c) {
+        const bool last_chunk = c + 1 == a.nchunk;
+        const bool stage_next = !last_chunk || has_next;
+        const TileGeo gs = last_chunk ? gn : g;
+        const int cs = last_chunk ? 0 : c + 1;
+        const char* pb = pbuf + pcur * PATCHB;
+        u32x4_t stg = {0, 0, 0, 0};
+        int sj = 0;
+        uint32_t xaddr[FI];
+        auto x_addr = [&](int toff) {
+#pragma unroll
+          for (int i = 0; i < FI; ++i) {
+            const int prow = lbase[i] + toff;
+            xaddr[i] = (uint32_t)(prow * 128 + ((fg ^ (prow & 7)) << 4));
+          }
+        };
+        auto x_load8 = [&](v8i_t (&xf)[FP8 ? FI : 1]) {
+#pragma unroll
+          for (int i = 0; i < (FP8 ? FI : 1); ++i) {
+            const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(pb + xaddr[i]), hi = *reinterpret_cast<const u32x4_t*>(pb + (xaddr[i] ^ 64u));
+            xf[i] = __builtin_shufflevector(__builtin_bit_cast(v4i_t, lo), __builtin_bit_cast(v4i_t, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+        };
+        auto mma8 = [&](const v8i_t (&wf)[FP8 ? FJ : 1], const v8i_t (&xf)[FP8 ? FI : 1], int i0, int i1) {
+#pragma unroll
+          for (int i = 0; i < (FP8 ? FI : 1); ++i)
+            if (i >= i0 && i < i1) {
+#pragma unroll
+              for (int j = 0; j < (FP8 ? FJ : 1); ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], xf[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            }
+        };
+        auto step = [&](auto par_tag, int t) {
+          constexpr int P = decltype(par_tag)::value;
+          const bool last_tap = t + 1 == a.ntaps;
+          const int nt = last_tap ? 0 : t + 1;
+          const int nc = last_tap ? (last_chunk ? 0 : c + 1) : c;
+          const int nn0 = (last_tap && last_chunk) ? gn.n0 : g.n0;
+          const int kb_next = kb_of(nc, nt);
+          const int toff_next = taptab[last_tap ? t : t + 1];
+          __builtin_amdgcn_sched_barrier(0);
+          mma8(W8[P], X8[P], 0, FI / 2);               // waits for this tap's operands (issued one tap ago) land here
+          __builtin_amdgcn_sched_barrier(0);
+          w_load8(nn0, kb_next, W8[P ^ 1]);            // next tap, else first tap of the next slab / tile
+          x_addr(toff_next);                           // after the last tap: a harmless re-read (the next slab's activations wait for
+          x_load8(X8[P ^ 1]);                          // the barrier and are read at its start); unconditional -> no register copies
+          if (stage_next) {
+            if (sj > 0 && sj <= NSLICE) slab_store(pcur ^ 1, sj - 1, stg);
+            if (sj < NSLICE) stg = slab_load(gs, cs, sj);
+            ++sj;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mma8(W8[P], X8[P], FI / 2, FI);
+        };
+        // every slab starts on set 0; the tap loop is unrolled by two and an odd last tap hands the prefetched weights over
+        x_addr(taptab[0]);
+        x_load8(X8[0]);
+        int t = 0;
+        for (; t + 1 < a.ntaps; t += 2) {
+          step(std::integral_constant<int, 0>{}, t);
+          step(std::integral_constant<int, 1>{}, t + 1);
+        }
+        if (t < a.ntaps) {
+          step(std::integral_constant<int, 0>{}, t);
+#pragma unroll
+          for (int j = 0; j < (FP8 ? FJ : 1); ++j) W8[0][j] = W8[1][j];
+        }
+        if (stage_next) {
+          while (sj <= NSLICE) {
+            if (sj > 0) slab_store(pcur ^ 1, sj - 1, stg);
+            if (sj < NSLICE) stg = slab_load(gs, cs, sj);
+            ++sj;
+          }
+        }
+        __syncthreads();
+        pcur ^= 1;
+        stamp();
+      }
     } else
     for (int c = 0; c < a.nchunk; ++c) {
       const bool last_chunk = c + 1 == a.nchunk;
@@ -360,6 +462,8 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
         bq[j] = (a.bias && n < a.Nst) ? *reinterpret_cast<const f32x4_t*>(a.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
       }
       const bool odd = fg & 1;
+      float oscale = 1.f;
+      if constexpr (FP8) oscale = a.w_scale[0] * (a.in_scale ? a.in_scale[g.b] : 1.f);
 #pragma unroll
       for (int i = 0; i < FI; ++i) {
         const int m = g.m0 + wm * (16 * FI) + i * 16 + fr;
@@ -373,7 +477,7 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float t = acc[i][j][e] + bq[j][e];
+            const float t = FP8 ? acc[i][j][e] * oscale + bq[j][e] : acc[i][j][e] + bq[j][e];
             if constexpr (STATS) { const float tm = mok ? t : 0.f; ssum[4 * j + e] += tm; ssq[4 * j + e] += tm * tm; }
             v[e] = ACT == GAN_ACT_RELU ? fmaxf(t, 0.f) : ACT == GAN_ACT_LRELU ? (t > 0.f ? t : 0.2f * t) : ACT == GAN_ACT_TANH ? tanhf(t) : t;
           }
@@ -467,6 +571,7 @@ static int patch_tile_rows(const gan_conv_desc* d, bool planning = false) {
   int BM = 0, forced = 0;
   int64_t best = 0;
   if (!planning && (d->tile_rows == 256 || d->tile_rows == 288) && patch_span(d, d->tile_rows) <= RMAX) return d->tile_rows;
+  if (d->dtype == GAN_FP8) return 256;
   if (planning) { const char* e = getenv("GAN_PATCH_BM"); forced = e ? atoi(e) : 0; }
   for (int cand : {256, 288}) {
     if (patch_span(d, cand) > RMAX || (forced && forced != cand && patch_span(d, forced) <= RMAX)) continue;
@@ -484,7 +589,10 @@ extern "C" int gan_conv_patch_ok(const gan_conv_desc* d) {
   if (disabled < 0) { const char* e = getenv("GAN_NO_PATCH"); disabled = (e && atoi(e)) ? 1 : 0; }
   if (disabled || !d) return 0;
   if (d->mask && d->act != GAN_ACT_NONE) return 0;   // the masked epilogue is specialised for act = none
-  if (d->dtype != GAN_BF16 || d->Cin < 64 || d->Cin % 64 != 0 || d->Nw % BN != 0 || d->Nst % 8 != 0 || d->out_C % 8 != 0) return 0;
+  const bool fp8 = d->dtype == GAN_FP8;
+  const int slots = fp8 ? d->Cin / 2 : d->Cin;             // 2-byte slots per pixel (fp8: two channels per slot)
+  if ((d->dtype != GAN_BF16 && !fp8) || slots < 64 || slots % 64 != 0 || d->Nw % BN != 0 || d->Nst % 8 != 0 || d->out_C % 8 != 0) return 0;
+  if (fp8 && (d->mask || !d->w_scale || patch_span(d, 256) > RMAX)) return 0;   // fp8: 256-row tile, plain epilogue
   if (d->max_tapoff <= 0 || d->ntaps < 1) return 0;
   if (!(patch_span(d, 256) <= RMAX || patch_span(d, 288) <= RMAX)) return 0;
   // tile utilisation: a map of 324 pixels (18x18 input-gradient domain of a 16x16 layer) fills 63 % of two 256-row tiles -- the
@@ -518,8 +626,11 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   a.in = (const char*)d->in; a.w = (const char*)d->w; a.bias = d->bias; a.out = (char*)d->out; a.mask = (const char*)d->mask; a.tapoff = d->tapoff;
   a.B = d->B; a.M_img = M_img; a.Wo = d->Wo; a.MT_img = (M_img + BM - 1) / BM; a.NTILES = (d->Nst + BN - 1) / BN;
   a.tiles = a.B * a.MT_img * a.NTILES;
-  a.Cin = d->Cin; a.nchunk = d->Cin / 64; a.ntaps = d->ntaps; a.KB = d->ntaps * d->Cin / 32;
-  a.w_bytes = d->Nw * d->ntaps * d->Cin * 2;
+  const bool fp8 = d->dtype == GAN_FP8;
+  a.Cin = fp8 ? d->Cin / 2 : d->Cin;          // 2-byte slots per pixel and tap
+  a.tapdiv = d->Cin; a.w_scale = d->w_scale; a.in_scale = d->in_scale;
+  a.nchunk = a.Cin / 64; a.ntaps = d->ntaps; a.KB = d->ntaps * a.Cin / 32;
+  a.w_bytes = d->Nw * d->ntaps * a.Cin * 2;
   a.in_Hp = d->in_Hp; a.in_Wp = d->in_Wp; a.in_y0 = d->in_y0; a.in_x0 = d->in_x0; a.in_sy = d->in_sy; a.in_sx = d->in_sx;
   a.in_pix = d->B * d->in_Hp * d->in_Wp;
   a.out_Hp = d->out_Hp; a.out_Wp = d->out_Wp; a.out_C = d->out_C; a.out_y0 = d->out_y0; a.out_x0 = d->out_x0; a.out_sy = d->out_sy; a.out_sx = d->out_sx;
@@ -539,7 +650,8 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
     if (hipFuncSetAttribute((const void*)conv_patch_kernel<256, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)conv_patch_kernel<288, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv_patch_kernel<256, 2, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+        hipFuncSetAttribute((const void*)conv_patch_kernel<256, 2, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv_patch_kernel<256, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return gan_set_error(-2, "conv_patch: cannot raise the dynamic LDS limit to %d bytes", LDS_BYTES);
     attr_devs.fetch_or(dev_bit, std::memory_order_release);
   }
@@ -547,7 +659,9 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   // stream clocks lower (2.04 -> 1.88 GHz), so the forward gains 3 % wall (69.5 -> 67.2 us = 1.15 PFLOP/s); on the 288-row tile,
   // whose 9 fragment addresses per tap do not fit in registers, it lost 9 % and is not instantiated.
   const bool st9 = BM == 256 && d->ntaps == 9 && a.nchunk % 2 == 0 && !static_off;
-  if (BM == 256) {
+  if (fp8) {
+    hipLaunchKernelGGL((conv_patch_kernel<256, 2, 0, true>), dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
+  } else if (BM == 256) {
     if (st9) hipLaunchKernelGGL((conv_patch_kernel<256, 2, 9>), dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<256, 2, 0>), dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
   } else {

@@ -273,6 +273,34 @@ __device__ __forceinline__ void pack_one(const gan_pack_desc& D, int lb) {
     st1<T>(dst + o, v);
   }
 }
+// e4m3 operand copy (dtype GAN_FP8), dst = e4m3(src / *scale).  Layout 1: the fragment-major image of the bf16 kernel with TWO fp8
+// channels in every 2-byte slot -- element (n, k) lives at byte 2 * slot(n, k / 2) + (k & 1), slot() as for bf16 over Cin / 2
+// "pseudo channels" -- so the range-patch kernel moves exactly the bytes it moves for bf16 and feeds them to the 128-deep fp8 MFMA.
+__device__ __forceinline__ void pack_one_fp8(const gan_pack_desc& D, int lb) {
+  const float* __restrict__ src = D.src;
+  uint8_t* __restrict__ dst = reinterpret_cast<uint8_t*>(D.dst);
+  const float inv = 1.f / *D.scale;
+  const int64_t total4 = (int64_t)D.Nw * D.ntaps * D.Cin / 4;          // four consecutive channels (one dword) per thread step
+  for (int64_t i4 = lb * (int64_t)blockDim.x + threadIdx.x; i4 < total4; i4 += (int64_t)D.nblocks * blockDim.x) {
+    const int64_t i = i4 * 4;
+    const int c = (int)(i % D.Cin);
+    const int t = (int)((i / D.Cin) % D.ntaps);
+    const int n = (int)(i / ((int64_t)D.Cin * D.ntaps));
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const int k = D.khw[t];
+    if (n < D.N_real && k >= 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < D.C_real) v[e] = src[D.swap ? ((int64_t)(c + e) * D.I2 + n) * D.KK + k : ((int64_t)n * D.I2 + c + e) * D.KK + k] * inv;
+    }
+    int64_t o = i;
+    if (D.layout == 1) {
+      const int Cp = D.Cin / 2, kk = t * Cp + c / 2, KB = D.ntaps * Cp / 32;     // c is a multiple of 4: two whole pseudo slots
+      o = 2 * (((((int64_t)(n >> 4) * KB + (kk >> 5)) * 64) + ((kk & 31) >> 3) * 16 + (n & 15)) * 8 + (kk & 7));
+    }
+    *reinterpret_cast<uint32_t*>(dst + o) = f2e4m3x4(v[0], v[1], v[2], v[3]);
+  }
+}
 __global__ __launch_bounds__(256) void pack_batch_kernel(const gan_pack_desc* __restrict__ d, int n) {
   int lo = 0, hi = n - 1;
   const int blk = blockIdx.x;
@@ -283,7 +311,9 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const gan_pack_desc* __
   const gan_pack_desc D = d[lo];
   const int lb = blk - D.first_block;
   if (lb >= D.nblocks) return;
-  if (D.dtype == GAN_BF16) pack_one<bf16_t>(D, lb); else pack_one<float>(D, lb);
+  if (D.dtype == GAN_FP8) pack_one_fp8(D, lb);
+  else if (D.dtype == GAN_BF16) pack_one<bf16_t>(D, lb);
+  else pack_one<float>(D, lb);
 }
 
 // column sums of g over logical pixels: stage 1 -> ws[block][C] (16-byte chunk loads, one chunk lane per 4/8 channels),
@@ -391,6 +421,7 @@ extern "C" int gan_wgrad_reduce(const float* part, int nsplit, int N, int ntaps,
 extern "C" int gan_pack_weight(const float* src, void* dst, int dtype, int Nw, int ntaps, int Cin, int N_real, int C_real, int swap,
                                int I2, int KK, const int32_t* khw, int layout, void* stream) {
   GAN_CHECK(src && dst && khw && N_real <= Nw && C_real <= Cin, "pack_weight: bad arguments");
+  GAN_CHECK(dtype == GAN_F32 || dtype == GAN_BF16, "pack_weight: dtype %d (fp8 copies need a scale: gan_pack_weight_batch)", dtype);
   GAN_CHECK(layout == 0 || (layout == 1 && Nw % 16 == 0 && (ntaps * Cin) % 32 == 0), "pack_weight: bad layout %d", layout);
   const int64_t total = (int64_t)Nw * ntaps * Cin;
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);

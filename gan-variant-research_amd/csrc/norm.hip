@@ -394,9 +394,10 @@ __global__ __launch_bounds__(NTHR, 6) void in_bwd_partial_kernel(DView x, const 
 // the column sum of dx, which is IDENTICALLY zero: sum_p dx = A S1 + Bc HW mean + HW Cc = rstd S1 - HW rstd (S1 / HW).  The reference's
 // autograd value is the rounding noise of that sum (|g| ~ 1e-9); here the sum is evaluated in closed form from the
 // same totals (fp64) by the image's first block -- the other blocks' rows are zero -- instead of being re-accumulated per element.
-template <typename T, int UNR, int ACT, bool FOLD>
+// AMAX: additionally amax[b] = max(amax[b], max |dx| of this block) (atomic max on the bit patterns of non-negative floats: order-independent).
+template <typename T, int UNR, int ACT, bool FOLD, bool AMAX = false>
 __global__ __launch_bounds__(NTHR, 6) void in_bwd_apply_kernel(DView x, const float* __restrict__ stats, DView gy, const float* __restrict__ ws, int nch,
-                                                           DView dx, int nblk, float* __restrict__ bias_part) {
+                                                           DView dx, int nblk, float* __restrict__ bias_part, float* __restrict__ amax = nullptr) {
   constexpr int N = Chunk<T>::N, NP = Pairs<T>::NP;
   Lanes<T> L(x.C);
   const int b = blockIdx.y, HW = x.H * x.W, cofs = L.cl * N;
@@ -421,6 +422,7 @@ __global__ __launch_bounds__(NTHR, 6) void in_bwd_apply_kernel(DView x, const fl
   T* dp = const_cast<T*>(image_ptr<T>(dx, b, cofs));
   int yy, xx; pixel_yx(p0 + L.rl, x.W, yy, xx);
   Off32 ox(x, yy, xx, L.RL, x.W), og(gy, yy, xx, L.RL, x.W), od(dx, yy, xx, L.RL, x.W);
+  float mx = 0.f;
   for (int p = p0 + L.rl; p < p1; p += UNR * L.RL) {
     Raw<T> xr[UNR], gr[UNR];
     int ods[UNR];
@@ -455,12 +457,18 @@ __global__ __launch_bounds__(NTHR, 6) void in_bwd_apply_kernel(DView x, const fl
         Pairs<T>::get(gr[u], j, ga, gb);
         ga = act_mask<ACT>(ga, xa, ca[0]) * ca[1] + (xa * ca[2] + ca[3]);
         gb = act_mask<ACT>(gb, xb, cb[0]) * cb[1] + (xb * cb[2] + cb[3]);
+        if (AMAX && ((live >> u) & 1)) mx = fmaxf(mx, fmaxf(fabsf(ga), fabsf(gb)));
         Pairs<T>::set(gr[u], j, ga, gb);
       }
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u)
       if ((live >> u) & 1) *reinterpret_cast<Raw<T>*>(dp + ods[u]) = gr[u];
+  }
+  if (AMAX) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax) + b, __builtin_bit_cast(unsigned, mx));
   }
 }
 // out[seg][c] (+)= sum over this segment's blocks of part[blk][c]; gridDim.y segments (two-level reduction: many partials,
@@ -623,6 +631,7 @@ __global__ void view_copy_kernel(DView src, DView dst, int halo_mode) {
 }
 
 int check_lanes(const gan_view* v, const char* what) {
+  if (v->dtype != GAN_F32 && v->dtype != GAN_BF16) return gan_set_error(-1, "%s: dtype %d (these passes run on fp32 / bf16 buffers; fp8 is an operand-copy format)", what, v->dtype);
   const int epc = v->dtype == GAN_F32 ? 4 : 8;
   const int cl = v->C / epc;
   if (v->C % epc != 0 || cl > NTHR || (cl & (cl - 1)) != 0) return gan_set_error(-1, "%s: C=%d unsupported (C/%d must be a power of two <= 256)", what, v->C, epc);
@@ -778,7 +787,7 @@ extern "C" int gan_in_apply_parts(const gan_view* x, const float* parts, int npa
 
 // ws: fp32, >= B*MAXCH*C*2 + B*C*2 floats
 static int in_bwd_impl(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2, const gan_view* dx,
-                       float* ws, float* bias_grad, int bias_n, int bias_acc, void* stream, float* bias_part = nullptr);
+                       float* ws, float* bias_grad, int bias_n, int bias_acc, void* stream, float* bias_part = nullptr, float* amax = nullptr);
 
 extern "C" int gan_in_bwd(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2,
                           const gan_view* dx, float* ws, void* stream) {
@@ -794,7 +803,7 @@ extern "C" int gan_in_bwd_bias(const gan_view* x, const float* stats, int act, c
 }
 
 static int in_bwd_impl(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2, const gan_view* dx,
-                       float* ws, float* bias_grad, int bias_n, int bias_acc, void* stream, float* bias_part) {
+                       float* ws, float* bias_grad, int bias_n, int bias_acc, void* stream, float* bias_part, float* amax) {
   VCHK(x, "in_bwd.x"); VCHK(gy, "in_bwd.gy"); VCHK(dx, "in_bwd.dx");
   if (check_lanes(x, "in_bwd")) return -1;
   SAME_SHAPE(x, gy, "in_bwd(x,gy)"); SAME_SHAPE(x, dx, "in_bwd(x,dx)");
@@ -822,7 +831,8 @@ static int in_bwd_impl(const gan_view* x, const float* stats, int act, const gan
       constexpr int ACT = decltype(act_c)::value;
       constexpr bool FOLD = decltype(fold_c)::value;
       hipLaunchKernelGGL((in_bwd_partial_kernel<T, U, ACT, FOLD>), dim3(nch, x->B), dim3(NTHR), 0, s, vx, stats, vg, nch, ws);
-      hipLaunchKernelGGL((in_bwd_apply_kernel<T, U, ACT, FOLD>), dim3(nblk, x->B), dim3(NTHR), 0, s, vx, stats, vg, ws, nch, vd, nblk, bp);
+      if (amax) hipLaunchKernelGGL((in_bwd_apply_kernel<T, U, ACT, FOLD, true>), dim3(nblk, x->B), dim3(NTHR), 0, s, vx, stats, vg, ws, nch, vd, nblk, bp, amax);
+      else hipLaunchKernelGGL((in_bwd_apply_kernel<T, U, ACT, FOLD>), dim3(nblk, x->B), dim3(NTHR), 0, s, vx, stats, vg, ws, nch, vd, nblk, bp, (float*)nullptr);
     };
     using std::integral_constant;
     if (fold) {
@@ -860,6 +870,13 @@ extern "C" int gan_in_bwd_bias_deferred(const gan_view* x, const float* stats, i
                                         const gan_view* dx, float* ws, float* bias_part, void* stream) {
   GAN_CHECK(bias_part, "in_bwd_bias_deferred: null partial buffer");
   return in_bwd_impl(x, stats, act, gy, fold, g2, dx, ws, nullptr, 0, 0, stream, bias_part);
+}
+
+extern "C" int gan_in_bwd_amax(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* dx, float* ws,
+                               float* bias_part, float* amax, void* stream) {
+  GAN_CHECK(amax, "in_bwd_amax: null amax");
+  if (hipMemsetAsync(amax, 0, sizeof(float) * (x ? x->B : 0), (hipStream_t)stream) != hipSuccess) return gan_set_error(-2, "in_bwd_amax: memset failed");
+  return in_bwd_impl(x, stats, act, gy, fold, nullptr, dx, ws, nullptr, 0, 0, stream, bias_part, amax);
 }
 
 extern "C" int gan_bias_finalize_batch(const gan_bias_part_desc* descs, int n, int total_blocks, void* stream) {

@@ -17,8 +17,8 @@ extern "C" int gan_version(void) { return 100; }
 
 int gan_check_view(const gan_view* v, const char* name) {
   if (!v || !v->ptr) return gan_set_error(-1, "%s: null view", name);
-  if (v->dtype != GAN_F32 && v->dtype != GAN_BF16) return gan_set_error(-1, "%s: bad dtype %d", name, v->dtype);
-  if (v->C <= 0 || v->C % 8 != 0) return gan_set_error(-1, "%s: C=%d must be a positive multiple of 8", name, v->C);
+  if (v->dtype != GAN_F32 && v->dtype != GAN_BF16 && v->dtype != GAN_FP8) return gan_set_error(-1, "%s: bad dtype %d", name, v->dtype);
+  if (v->C <= 0 || v->C % (v->dtype == GAN_FP8 ? 16 : 8) != 0) return gan_set_error(-1, "%s: C=%d must be a positive multiple of %d", name, v->C, v->dtype == GAN_FP8 ? 16 : 8);
   if (v->B <= 0 || v->H <= 0 || v->W <= 0 || v->y0 < 0 || v->x0 < 0 || v->y0 + v->H > v->Hp || v->x0 + v->W > v->Wp)
     return gan_set_error(-1, "%s: logical window %dx%d at (%d,%d) outside allocation %dx%d", name, v->H, v->W, v->y0, v->x0, v->Hp, v->Wp);
   if ((uintptr_t)v->ptr % 16 != 0) return gan_set_error(-1, "%s: pointer must be 16-byte aligned", name);

@@ -16,14 +16,14 @@ from typing import Callable, List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, BF16, F32, HALO_NONE, HALO_REFLECT, HALO_ZERO, GanAdamTensor, GanConvDesc, GanView, GanWgradDesc
+from ._lib import ACT_NONE, BF16, F32, FP8, HALO_NONE, HALO_REFLECT, HALO_ZERO, GanAdamTensor, GanConvDesc, GanView, GanWgradDesc
 
 IN_WS_CHUNKS = 96
 ADAM_CHUNK = 16384
 
 
 def torch_dtype(code: int):
-    return torch.float32 if code == F32 else torch.bfloat16
+    return torch.float32 if code == F32 else torch.uint8 if code == FP8 else torch.bfloat16      # FP8: raw e4m3 bytes
 
 
 class View:
@@ -32,7 +32,7 @@ class View:
     def __init__(self, t: torch.Tensor, B: int, H: int, W: int, C_: int, halo: int, dtype: int):
         self.t, self.B, self.H, self.W, self.C, self.halo, self.dtype = t, B, H, W, C_, halo, dtype
         self.Hp, self.Wp = H + 2 * halo, W + 2 * halo
-        assert t.numel() == B * self.Hp * self.Wp * C_ and C_ % 8 == 0
+        assert t.numel() == B * self.Hp * self.Wp * C_ and C_ % (16 if dtype == FP8 else 8) == 0
         self._struct = None
 
     @property
@@ -97,6 +97,8 @@ class ConvCall:
     tile_rows: int = 0        # range-patch kernel: pixels per tile, fixed at planning time (HipOps.conv_patch_tile_rows)
     stats: Optional[torch.Tensor] = None   # InstanceNorm partials written by the epilogue (see HipOps.conv_stats_parts)
     win7: Optional[tuple] = None           # (ty0, tx0): run by the 7x7 window kernel, taps row-major from that position (w_layout 2)
+    w_scale: Optional[torch.Tensor] = None  # fp8 operands: device float, dequantisation scale of the weight copy
+    in_scale: Optional[torch.Tensor] = None  # fp8 operands: device float[B], per-image scale of the input copy (None: 1)
     flop_scale: float = 1.0                # algorithmic / launched FLOPs (paired phases multiply by zero blocks: 0.75); bench.py prices with it
     alg_pixels: Optional[int] = None       # output pixels per image of the REFERENCE op this launch implements, when they differ from Ho*Wo
                                            # (stride-1 input gradients run on the input's -- possibly reflect-padded -- domain); SURVEY §8d
@@ -280,10 +282,12 @@ class HipOps:
         d.max_tapoff = c.max_tapoff
         d.w_layout = 1 if c.w_frag else 0
         d.tile_rows = c.tile_rows
+        d.w_scale = c.w_scale.data_ptr() if c.w_scale is not None else None
+        d.in_scale = c.in_scale.data_ptr() if c.in_scale is not None else None
         if c.win7 is not None:
             assert not c.w_frag
             d.w_layout, d.win_ty0, d.win_tx0 = 2, c.win7[0], c.win7[1]
-        assert c.out.dtype == c.x.dtype
+        assert c.out.dtype == (BF16 if c.x.dtype == FP8 else c.x.dtype)       # fp8 operands produce a bf16 result
         return d
 
     def conv_patch_ok(self, c: ConvCall) -> bool:
@@ -343,25 +347,46 @@ class HipOps:
         return self._call("gan_wgrad_reduce", self._p(part), nsplit, N, ntaps, Cx, N_real, C_real, int(swap), I2, KK, self._p(khw),
                           self._p(grad), int(accumulate), self._s())
 
-    def pack_weight(self, src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, swap, I2, KK, khw, layout=0) -> Op:
-        op = self._call("gan_pack_weight", self._p(src), self._p(dst), dtype, Nw, ntaps, Cin, N_real, C_real, int(swap), I2, KK,
-                        self._p(khw), int(layout), self._s())
-        op.pack_args = (src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, int(swap), I2, KK, khw, int(layout))
+    def pack_weight(self, src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, swap, I2, KK, khw, layout=0, scale=None) -> Op:
+        """One operand copy.  dtype FP8 (e4m3, needs `scale`: a device float the batch launch fills with max|W| / 448) exists only in
+        the batched form: the returned op then only carries its arguments for pack_weight_batch."""
+        if dtype == FP8:
+            assert scale is not None and layout == 1
+
+            def op():
+                raise _lib.GanError("fp8 operand copies are packed by pack_weight_batch")
+        else:
+            op = self._call("gan_pack_weight", self._p(src), self._p(dst), dtype, Nw, ntaps, Cin, N_real, C_real, int(swap), I2, KK,
+                            self._p(khw), int(layout), self._s())
+        op.pack_args = (src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, int(swap), I2, KK, khw, int(layout), scale)
         return op
 
     def pack_weight_batch(self, packs) -> Op:
         """One launch for many operand copies; `packs` = the pack_args tuples of ops built by pack_weight."""
         arr = (_lib.GanPackDesc * len(packs))()
         first = 0
-        for d, (src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, swap, I2, KK, khw, layout) in zip(arr, packs):
+        any_fp8 = False
+        for d, (src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, swap, I2, KK, khw, layout, *rest) in zip(arr, packs):
             assert layout == 0 or (Nw % 16 == 0 and (ntaps * Cin) % 32 == 0)
-            self._keep.extend((src, dst, khw))
+            scale = rest[0] if rest else None
+            self._keep.extend((src, dst, khw, scale))
             d.src, d.dst, d.khw = src.data_ptr(), dst.data_ptr(), khw.data_ptr()
+            d.scale = scale.data_ptr() if scale is not None else None
+            any_fp8 = any_fp8 or dtype == FP8
             d.dtype, d.Nw, d.ntaps, d.Cin, d.N_real, d.C_real, d.swap, d.I2, d.KK, d.layout = dtype, Nw, ntaps, Cin, N_real, C_real, swap, I2, KK, layout
             d.nblocks = max(1, min(512, (Nw * ntaps * Cin + 1023) // 1024))
             d.first_block, first = first, first + d.nblocks
         table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-        return self._call("gan_pack_weight_batch", self._p(table), len(packs), first, self._s())
+        pack = self._call("gan_pack_weight_batch", self._p(table), len(packs), first, self._s())
+        if not any_fp8:
+            return pack
+        scales = self._call("gan_weight_scale_batch", self._p(table), len(packs), self._s())   # per-tensor max|W| / 448 first
+
+        def op():
+            scales()
+            pack()
+        op.__name__ = "gan_pack_weight_batch"
+        return op
 
     def bias_grad(self, g: View, N_real, grad, accumulate, ws) -> Op:
         return self._call("gan_bias_grad", self._v(g), N_real, self._p(grad), int(accumulate), self._p(ws), self._s())
@@ -426,6 +451,17 @@ class HipOps:
             d.first_block, first = first, first + (Cc + 31) // 32
         table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
         return self._call("gan_bias_finalize_batch", self._p(table), len(items), first, self._s())
+
+    def in_bwd_amax(self, x: View, stats, act, gy: View, fold, dx: View, ws, bias_part, amax) -> Op:
+        """InstanceNorm backward that also leaves max|dx| per image in `amax` (float[B]): the scale of dx's e4m3 copy."""
+        assert amax.dtype == torch.float32 and amax.numel() >= x.B
+        return self._hbm(self._call("gan_in_bwd_amax", self._v(x), self._p(stats), act, self._v(gy), int(fold), self._v(dx), self._p(ws),
+                                    self._p(bias_part), self._p(amax), self._s()), x, 3)
+
+    def quantize_fp8(self, src: View, dst: View, amax=None, scale_out=None) -> Op:
+        """e4m3 copy of a whole buffer (halo included): unit scale, or per-image scale amax[b] / 448 written to scale_out[b]."""
+        assert dst.dtype == FP8 and (src.B, src.Hp, src.Wp, src.C, src.halo) == (dst.B, dst.Hp, dst.Wp, dst.C, dst.halo)
+        return self._call("gan_quantize_fp8", self._v(src), self._v(dst), self._p(amax), self._p(scale_out), self._s())
 
     def fold_add(self, a: Optional[View], b: View, fold, out: View) -> Op:
         return self._call("gan_fold_add", self._v(a), self._v(b), int(fold), self._v(out), self._s())

@@ -19,7 +19,10 @@
 extern "C" {
 #endif
 
-enum { GAN_F32 = 0, GAN_BF16 = 1 };
+/* GAN_FP8: OCP e4m3 ("e4m3fn": no infinities, max 448), one byte per element.  Only operand COPIES of the bottleneck convolutions are
+ * fp8 (BASELINE.json configs[4]): gan_quantize_fp8 writes activations / output gradients, gan_pack_weight the weights; every result,
+ * statistic and master weight stays bf16 / fp32.  An fp8 view has C % 16 == 0. */
+enum { GAN_F32 = 0, GAN_BF16 = 1, GAN_FP8 = 2 };
 enum { GAN_ACT_NONE = 0, GAN_ACT_RELU = 1, GAN_ACT_LRELU = 2, GAN_ACT_TANH = 3 };
 enum { GAN_HALO_NONE = 0, GAN_HALO_ZERO = 1, GAN_HALO_REFLECT = 2 };
 
@@ -68,6 +71,11 @@ typedef struct gan_conv_desc {
   int32_t tile_rows;             /* w_layout 1: output pixels per tile (256 or 288), fixed by the planner with gan_conv_patch_tile_rows so
                                     that the launch and the partial count of `stats` (gan_conv_stats_parts) agree; 0: chosen at launch */
   int32_t _pad;
+  /* dtype GAN_FP8 (range-patch kernel only, w_layout 1): `in` and `w` hold e4m3 bytes, `out` / `mask` / `bias` are as for GAN_BF16
+   * (the result is bf16).  result = act(acc * w_scale[0] * (in_scale ? in_scale[b] : 1) + bias): the dequantisation scales of the
+   * weight copy (gan_weight_scale_batch) and of image b of the input copy (gan_quantize_fp8), both device pointers. */
+  const float* w_scale;
+  const float* in_scale;
 } gan_conv_desc;
 
 /* Weight-gradient GEMM: part[s][n][t][c] = sum over the rows m of split s of
@@ -130,8 +138,18 @@ int gan_pack_weight(const float* src, void* dst, int dtype, int Nw, int ntaps, i
 typedef struct gan_pack_desc {
   const float* src; void* dst; const int32_t* khw;
   int32_t dtype, Nw, ntaps, Cin, N_real, C_real, swap, I2, KK, layout, first_block, nblocks;
+  float* scale;                  /* dtype GAN_FP8: device float, dst = e4m3(src / *scale); written by gan_weight_scale_batch; else unused */
 } gan_pack_desc;
 int gan_pack_weight_batch(const gan_pack_desc* descs, int n, int total_blocks, void* stream);
+/* For every descriptor with dtype GAN_FP8: *scale = max|src| / 448 over the whole master weight ((swap ? C_real : N_real) * I2 * KK
+ * floats), 1 if the weight is all zero -- the per-tensor dequantisation scale of the e4m3 operand copy.  One launch for the batch
+ * (same DEVICE descriptor array as gan_pack_weight_batch, which it precedes). */
+int gan_weight_scale_batch(const gan_pack_desc* descs, int n, void* stream);
+/* e4m3 operand copy of an activation / gradient buffer: dst (GAN_FP8) has exactly src's (GAN_BF16 / GAN_F32) geometry (B, Hp, Wp, C,
+ * halo) and the WHOLE allocation is converted, halo included (the producer already materialised it).  amax == NULL: dst = e4m3(src)
+ * (unit scale: InstanceNorm outputs are O(1)).  amax != NULL: device float[B] holding max|src| per image (gan_in_bwd_amax); then
+ * scale_out[b] = amax[b] / 448 (1 if zero) and dst = e4m3(src / scale_out[b]).  Values are clamped to +-448 before conversion. */
+int gan_quantize_fp8(const gan_view* src, const gan_view* dst, const float* amax, float* scale_out, void* stream);
 /* bias gradient: grad[n] (+)= sum over logical pixels of g[...,n], n < N_real (column sums of dY) */
 int gan_bias_grad(const gan_view* g, int N_real, float* grad, int accumulate, float* ws, void* stream);
 
@@ -175,6 +193,10 @@ int gan_in_bwd_bias_parts(const gan_view* x);
 int gan_in_bwd_bias_deferred(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2,
                              const gan_view* dx, float* ws, float* bias_part, void* stream);
 int gan_bias_finalize_batch(const gan_bias_part_desc* descs, int n, int total_blocks, void* stream);
+/* gan_in_bwd_bias_deferred (bias_part may be NULL: no bias gradient) that also leaves max|dx| per image in amax[B] (device floats,
+ * combined with atomic max on the bit patterns -- order-independent, hence deterministic): the scale of dx's e4m3 copy */
+int gan_in_bwd_amax(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* dx, float* ws,
+                    float* bias_part, float* amax, void* stream);
 int gan_fold_add(const gan_view* a, const gan_view* b, int fold, const gan_view* out, void* stream);
 /* dx = g * act'(y) (tanh: 1-y^2, lrelu: y>0?1:0.2), g optionally folded; written to the interior of dx */
 int gan_act_bwd(const gan_view* y, int act, const gan_view* g, int fold, const gan_view* g2, const gan_view* dx, void* stream);

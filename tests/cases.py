@@ -205,3 +205,57 @@ def run_basic_iterations(device, ops, amp=False, S=32, B=2, niter=2, tol0=2e-4, 
         for k in ref:
             np.testing.assert_allclose(got[k], ref[k], rtol=tol0 if it == 0 else tol1, atol=1e-5, err_msg=f"it{it} {k}")
     return tr
+
+
+def run_conv_fp8(ctx, B=2, C_=256, H=16, seed=0):
+    """The fp8 (e4m3) operand path of the bottleneck 3x3 256->256 convolution (BASELINE.json configs[4]): forward and input gradient
+    through gan_quantize_fp8 + gan_pack_weight_batch(FP8) + gan_conv_igemm(dtype FP8) against
+      (a) F.conv2d on the SAME e4m3-rounded operands (what the kernel must compute exactly, up to fp32 summation order and the bf16
+          rounding of the result: rtol 1e-2 of the output's rms), and
+      (b) F.conv2d on the unrounded operands with the fp8 tolerance: e4m3 keeps 3 mantissa bits (relative rounding error <= 2^-4 per
+          operand), which over K = 2304 random-sign products is ~4 % of the output's rms -> bound 0.12 * rms elementwise."""
+    from gan_variant_research_amd import FP8
+    from tests.emulator import _e4m3
+    dev = ctx.device
+    g = torch.Generator().manual_seed(seed)
+    w = (torch.rand(C_, C_, 3, 3, generator=g) * 2 - 1) / (C_ * 9) ** 0.5
+    b = torch.randn(C_, generator=g) * 0.1
+    x = torch.randn(B, C_, H, H, generator=g).bfloat16().float()
+    layer = ConvLayer(ctx, w.to(dev), b.to(dev), torch.zeros_like(w).to(dev), torch.zeros_like(b).to(dev), 3, 1, 1)
+    xv = to_view(ctx, x, 1, HALO_REFLECT)
+    x8 = ctx.view(B, H, H, C_, 1, dtype=FP8)
+    y = ctx.view(B, H, H, C_, 0)
+    ops_f = [ctx.ops.quantize_fp8(xv, x8)] + layer.fwd8(x8, y)
+    # input gradient: dY with a per-image scale, zero halo 2, padded-domain result folded by the consumer
+    dy = torch.randn(B, C_, H, H, generator=g) * torch.tensor([1e-3, 3e-5])[:B].view(B, 1, 1, 1)
+    dy = dy.bfloat16().float()
+    dyv = to_view(ctx, dy, 2, HALO_ZERO)
+    dy8 = ctx.view(B, H, H, C_, 2, dtype=FP8)
+    amax = dy.abs().amax((1, 2, 3)).to(dev)
+    scale = torch.zeros(B, device=dev)
+    dxp = ctx.view(B, H, H, C_, 1)
+    dxf = ctx.view(B, H, H, C_, 0)
+    ops_b = [ctx.ops.quantize_fp8(dyv, dy8, amax, scale)] + layer.dgrad8(dy8, dxp, scale, padded_domain=True) + [ctx.ops.fold_add(None, dxp, True, dxf)]
+    for o in [ctx.ops.pack_weight_batch([op.pack_args for op in layer.repack_ops()])] + ops_f + ops_b:
+        o()
+    if ctx.device.type == "cuda":
+        torch.cuda.synchronize()
+    sw = float(w.abs().max()) / 448.0
+    w8 = _e4m3(w / sw) * sw
+    xp = F.pad(x, (1, 1, 1, 1), mode="reflect")
+    got = from_view(y, C_)
+    exact = F.conv2d(_e4m3(xp), w8, b)
+    full = F.conv2d(xp, w, b)
+    rms = float(full.pow(2).mean().sqrt())
+    assert float((got - exact).abs().max()) < 1e-2 * rms * 4, (float((got - exact).abs().max()), rms)
+    assert float((got - full).abs().max()) < 0.12 * rms * 2.5 and float((got - full).pow(2).mean().sqrt()) < 0.05 * rms
+    np.testing.assert_allclose(scale.cpu().numpy(), (amax.cpu() / 448.0).numpy(), rtol=1e-6)
+    # reference input gradient through autograd on the reflect-padded convolution
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), w, None).backward(dy)
+    gotd = from_view(dxf, C_)
+    for bi in range(B):
+        r = float(xr.grad[bi].pow(2).mean().sqrt())
+        assert float((gotd[bi] - xr.grad[bi]).pow(2).mean().sqrt()) < 0.06 * r, (bi, float((gotd[bi] - xr.grad[bi]).pow(2).mean().sqrt()), r)
+        assert float((gotd[bi] - xr.grad[bi]).abs().max()) < 0.3 * r
+    return got, gotd

@@ -64,6 +64,17 @@ def _store(view, vals, padded_coords=False):
         view.nhwc().copy_(vals.to(view.t.dtype))
 
 
+def _e4m3(v):
+    """fp32 -> OCP e4m3 (round to nearest even, clamped to +-448) -> fp32: what an e4m3 byte holds."""
+    return v.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+
+
+def _vfloat(view):
+    """A view's whole padded buffer as floats (fp8 views hold raw e4m3 bytes)."""
+    t = view.padded()
+    return t.view(torch.float8_e4m3fn).float() if view.dtype == 2 else t.float()
+
+
 class EmuOps:
     is_hip = False
 
@@ -92,7 +103,11 @@ class EmuOps:
 
     def conv_patch_ok(self, c):
         """Statement of gan_conv_patch_ok (csrc/conv_patch.hip)."""
-        if c.x.dtype != 1 or c.Cin < 64 or c.Cin % 64 or c.Nw % 128 or c.Nst % 8 or c.out.C % 8 or c.max_tapoff <= 0:
+        fp8 = c.x.dtype == 2
+        slots = c.Cin // 2 if fp8 else c.Cin
+        if c.x.dtype not in (1, 2) or slots < 64 or slots % 64 or c.Nw % 128 or c.Nst % 8 or c.out.C % 8 or c.max_tapoff <= 0:
+            return False
+        if fp8 and (c.mask is not None or c.w_scale is None):
             return False
         if c.mask is not None and c.act != ACT_NONE:
             return False
@@ -102,7 +117,7 @@ class EmuOps:
         jump = max(0, c.x.Wp * c.in_sy - c.Wo * c.in_sx)
         if (rows - 1) * c.in_sx + wraps * jump + c.max_tapoff // c.Cin + 1 > 448:
             return False
-        if c.B * (-(-m_img // 256)) <= 128:
+        if fp8 or c.B * (-(-m_img // 256)) <= 128:
             return True
         rows_used = min(-(-m_img // 256) * 256, -(-m_img // 288) * 288)       # tile utilisation >= 75 % once the CUs are full
         return 4 * m_img >= 3 * rows_used
@@ -154,23 +169,29 @@ class EmuOps:
         return op
 
     @staticmethod
-    def _unfrag(wf, Nw, K):
-        """fragment-major [Nw/16][K/32][fg 4][fr 16][8] -> row-major [Nw][K]"""
-        return wf.view(Nw // 16, K // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(Nw, K)
+    def _unfrag(wf, Nw, K, sub=1):
+        """fragment-major [Nw/16][K/32][fg 4][fr 16][8] (x `sub` values per slot: 2 for fp8) -> row-major [Nw][K * sub]"""
+        return wf.view(Nw // 16, K // 32, 4, 16, 8 * sub).permute(0, 3, 1, 2, 4).reshape(Nw, K * sub)
 
     def conv_igemm(self, c):
         def op():
-            x = c.x.padded().float()
+            x = _vfloat(c.x)
             Cin, Wp = c.Cin, c.x.Wp
             assert c.x.C == Cin
-            if c.w_frag:
+            if c.x.dtype == 2:         # e4m3 operands: fragment-major bytes, two channels per 2-byte slot; per-tensor / per-image scales
+                assert c.w_frag and self.conv_patch_ok(c)
+                wb = c.w.view(torch.float8_e4m3fn).float().view(-1, 2)                       # [slot][2]
+                w = self._unfrag(wb.reshape(-1), c.Nw, c.ntaps * Cin // 2, 2).view(c.Nw, c.ntaps, Cin) * float(c.w_scale)
+                if c.in_scale is not None:
+                    x = x * c.in_scale[:c.B].float().view(c.B, 1, 1, 1)
+            elif c.w_frag:
                 assert self.conv_patch_ok(c)
                 w = self._unfrag(c.w.float(), c.Nw, c.ntaps * Cin).view(c.Nw, c.ntaps, Cin)
             else:
                 w = c.w.view(c.Nw, c.ntaps, Cin).float()
             acc = torch.zeros(c.B, c.Ho, c.Wo, c.Nw)
             toff = c.tapoff.tolist()
-            bke = 32 if c.x.dtype == 0 else 64
+            bke = 32 if c.x.dtype == 0 else 128 if c.x.dtype == 2 else 64
             assert (c.ntaps * Cin) % bke == 0 and len(toff) == c.ntaps
             ys0 = c.in_y0 + torch.arange(c.Ho) * c.in_sy
             xs0 = c.in_x0 + torch.arange(c.Wo) * c.in_sx
@@ -262,8 +283,11 @@ class EmuOps:
             g.copy_(new)
         return op
 
-    def pack_weight(self, src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, swap, I2, KK, khw, layout=0):
+    def pack_weight(self, src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, swap, I2, KK, khw, layout=0, scale=None):
         def op():
+            if dtype == 2:      # e4m3 copy: per-tensor scale max|W| / 448 (statement of gan_weight_scale_batch + the fp8 pack)
+                am = float(src.abs().max())
+                scale.fill_(am / 448.0 if am > 0 else 1.0)
             out = torch.zeros(Nw, ntaps, Cin)
             s = src.reshape(-1).float()
             n_idx = torch.arange(N_real)[:, None]
@@ -273,11 +297,18 @@ class EmuOps:
                     continue
                 o = ((c_idx * I2 + n_idx) if swap else (n_idx * I2 + c_idx)) * KK + k
                 out[:N_real, t, :C_real] = s[o]
+            if dtype == 2:
+                assert layout == 1
+                K = ntaps * Cin // 2                                              # 2-byte slots per row
+                q = (out / float(scale)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+                q = q.view(Nw // 16, 16, K // 32, 4, 16).permute(0, 2, 3, 1, 4)     # [n16][k32][fg][fr][8 slots x 2 bytes]
+                dst.view(-1).copy_(q.reshape(-1))
+                return
             if layout == 1:
                 K = ntaps * Cin
                 out = out.view(Nw // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4)
             dst.view(-1).copy_(out.reshape(-1).to(dst.dtype))
-        op.pack_args = (src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, int(swap), I2, KK, khw, int(layout))
+        op.pack_args = (src, dst, dtype, Nw, ntaps, Cin, N_real, C_real, int(swap), I2, KK, khw, int(layout), scale)
         return op
 
     def pack_weight_batch(self, packs):
@@ -359,6 +390,25 @@ class EmuOps:
             for part, nparts, Cc, grad, n_real, acc in items:
                 s = part[:nparts * Cc].view(nparts, Cc).sum(0)[:n_real]
                 grad.copy_(grad + s if acc else s)
+        return op
+
+    def in_bwd_amax(self, x, stats, act, gy, fold, dx, ws, bias_part, amax):
+        """Statement of gan_in_bwd_amax: gan_in_bwd_bias_deferred plus max|dx| per image."""
+        inner = self.in_bwd_bias_deferred(x, stats, act, gy, fold, None, dx, ws, bias_part) if bias_part is not None else self.in_bwd(x, stats, act, gy, fold, None, dx, ws)
+
+        def op():
+            inner()
+            amax[:x.B].copy_(dx.nhwc().float().abs().amax((1, 2, 3)))
+        return op
+
+    def quantize_fp8(self, src, dst, amax=None, scale_out=None):
+        def op():
+            v = src.padded().float()
+            if amax is not None:
+                sc = torch.where(amax[:src.B] > 0, amax[:src.B] / 448.0, torch.ones_like(amax[:src.B]))
+                scale_out[:src.B].copy_(sc)
+                v = v / sc.view(src.B, 1, 1, 1)
+            dst.padded().copy_(v.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8))
         return op
 
     def fold_add(self, a, b, fold, out):

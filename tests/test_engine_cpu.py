@@ -150,3 +150,11 @@ def test_merged_identity_pass_equals_separate_passes_and_mode_switch():
                                        err_msg=f"step {step} {k}")
     worst = max(float((a.opt_G.params[k] - v).abs().max()) for k, v in b.opt_G.params.items())
     assert worst < 1.7e-3, worst     # four sign-like Adam steps of lr 2e-4: +lr in one run, -lr in the other, on weights whose gradient is rounding noise
+
+
+def test_fp8_conv_path_host_logic():
+    """fp8 operand copies + descriptor plumbing of the bottleneck convolution on the emulator (quantisation, per-tensor / per-image
+    scales, fragment-major e4m3 packing, padded-domain input gradient)."""
+    from gan_variant_research_amd import BF16
+    from gan_variant_research_amd.runtime import Ctx
+    cases.run_conv_fp8(Ctx(EmuOps(), "cpu", BF16))

@@ -441,6 +441,20 @@ def test_two_gpu_ranks_equal_one_rank(tmp_path):
         np.testing.assert_allclose(0.5 * (res[0]["losses"][k] + res[1]["losses"][k]), ref_losses[k], rtol=1e-3, atol=1e-4, err_msg=k)
 
 
+@pytest.mark.parametrize("H", [16, 24])
+def test_fp8_conv_path_hip(H):
+    """BASELINE.json configs[4]: the e4m3 operand path of the bottleneck 3x3 256->256 convolution (forward and input gradient) on
+    v_mfma_scale_f32_16x16x128_f8f6f4 -- against F.conv2d on the same e4m3-rounded operands (exact up to summation order / bf16 output
+    rounding), against the unrounded convolution within the stated fp8 tolerance (tests/cases.py:run_conv_fp8), and against the CPU
+    statement of the same launches."""
+    got, gotd = cases.run_conv_fp8(hip_ctx(BF16), H=H)
+    emu, emud = cases.run_conv_fp8(Ctx(EmuOps(), "cpu", BF16), H=H)
+    rms, rmsd = float(emu.pow(2).mean().sqrt()), emud.pow(2).mean((1, 2, 3)).sqrt()
+    assert float((got - emu).abs().max()) < 2e-2 * rms
+    for bi in range(got.shape[0]):
+        assert float((gotd[bi] - emud[bi]).abs().max()) < 2e-2 * float(rmsd[bi])
+
+
 def test_ops_library_hip(monkeypatch):
     """torch.ops.mi355x_gan.* on the kernels: the generator and discriminator assembled layer by layer from the op-level drop-in modules
     reproduce the reference's own outputs (golden) and the oracle's gradients; the fused clip+Adam+EMA op matches torch.optim.Adam."""
