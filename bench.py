@@ -26,6 +26,7 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
+PEAK_FP8_TFLOPS = 5000.0    # dense fp8 MFMA peak (v_mfma_scale_f32_16x16x128_f8f6f4), same guide
 GFLOP_PER_IMAGE = 935.9     # canonical algorithmic conv FLOPs of one step per image at 256^2 (identity on)
 
 
@@ -55,8 +56,11 @@ def dominant_kernel_roofline(trainer, iters=10):
     fp32 (--fp32): the same over every `conv_igemm_kernel` launch.  The single 3x3 256->256 forward (77.3 GFLOP at B=16) is
     reported beside it as `res_fwd_*`."""
     bf16 = trainer.amp.enabled
+    fp8 = getattr(trainer, "fp8", False)
     progs = [trainer.prog_gfwd, trainer.prog_d_compute, trainer.prog_d_update, trainer.prog_g_features, trainer.prog_g_adversarial, trainer.prog_g_features_bwd, trainer.prog_g_compute, trainer.prog_g_identity, trainer.prog_g_update]
     calls = [o for p in progs if p is not None for o in p.ops if getattr(o, "conv", None) is not None and (o.conv.w_frag or not bf16)]
+    if fp8:      # configs[4]: price the e4m3 launches of the kernel (the residual convolutions) against the dense fp8 peak
+        calls = [o for o in calls if o.conv.x.dtype == 2]
     flops = sum(o.conv.alg_flops() for o in calls)      # SURVEY §8d: 2*M*N*K with M the reference op's output pixels
 
     def timed(ops, n):
@@ -84,9 +88,9 @@ def dominant_kernel_roofline(trainer, iters=10):
     ms = timed(calls, iters)
     conv = trainer.G.c_blk[0][0]
     x, y = trainer.p1.acts[2], trainer.p1.raw[3][0]
-    res_ms = timed(conv.fwd(x, y), 20)
+    res_ms = timed(conv.fwd8(trainer.p1.in8[0], y) if fp8 else conv.fwd(x, y), 20)
     res_flops = 2.0 * x.B * y.H * y.W * conv.cout * conv.cin * 9   # x.B = 2 x batch while the identity pass rides in the generator pass
-    peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
+    peak = PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
     ach = flops / (ms * 1e-3) / 1e12
     # the HBM-bound side of the path: every InstanceNorm forward / backward launch of the step, replayed the same way;
     # achieved = algorithmic bytes (each operand tensor once) / elapsed
@@ -98,7 +102,7 @@ def dominant_kernel_roofline(trainer, iters=10):
                         "launches_per_step": len(norm), "bytes_per_step": norm_bytes, "ms_per_step": round(norm_ms, 4)}
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": pmc_traffic("conv_patch_kernel") if bf16 else None,
-            "kernel": "conv_patch_kernel" if bf16 else "conv_igemm_kernel<float,...>",
+            "kernel": ("conv_patch_kernel<..., FP8> (e4m3 launches)" if fp8 else "conv_patch_kernel") if bf16 else "conv_igemm_kernel<float,...>",
             "launches_per_step": len(calls), "flop_per_step": flops, "ms_per_launch": round(ms / max(len(calls), 1), 5),
             "share_of_step_conv_flop": round(flops / (GFLOP_PER_IMAGE * 1e9 * trainer.B), 3),
             "res_fwd_tflops": round(res_flops / (res_ms * 1e-3) / 1e12, 2), "res_fwd_ms": round(res_ms, 4)}
@@ -193,6 +197,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--fp32", action="store_true", help="parity mode (exact fp32 MFMA) instead of bf16")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE.json configs[4]: e4m3 operand copies for the residual convolutions (forward, dgrad); "
+                                                       "use with --size 512 --batch 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["cut", "basic"], default="cut",
                     help="cut: BASELINE.json configs[2] (the metric's config); basic: configs[1], Basic_GAN CycleGAN 64x64 batch 256")
@@ -254,7 +260,7 @@ def main():
     cfg = default_config()
     C.set_seed(42)                                       # identical replicas on every rank
     gen, disc = C.build_models(cfg, dev)
-    tr = C.CutTrainer(gen, disc, cfg, args.batch, args.size, device=dev, amp=not args.fp32, ops=ops, world_size=world, process_group=pg)
+    tr = C.CutTrainer(gen, disc, cfg, args.batch, args.size, device=dev, amp=not args.fp32, ops=ops, world_size=world, process_group=pg, fp8=args.fp8)
     if force_dist and not os.environ.get("GAN_FORCE_DIST_NOAR"):
         tr.force_allreduce = True
     g = torch.Generator().manual_seed(1234 + rank)
@@ -297,9 +303,10 @@ def main():
         out = {
             "metric": f"images/sec (G+D train step) {args.size}x{args.size} CUT", "value": round(ips, 3), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.fp32 else ("fp8-e4m3 (residual convolutions: forward, dgrad) + bf16" if args.fp8 else "bf16"),
+            "data": "synthetic",
             "config": {"workload": f"CUT ResNet-9 G + PatchGAN D + PatchNCE + identity + lazy R1 + DiffAugment, {args.size}x{args.size}, "
-                                   f"batch {args.batch} per GPU (BASELINE.json configs[2])", "global_batch": args.batch * world,
+                                   f"batch {args.batch} per GPU (BASELINE.json configs[{4 if args.fp8 else 2}])", "global_batch": args.batch * world,
                        "parallelism": f"dp{world}"},
             "step_mfma_frac": round(ips / world * GFLOP_PER_IMAGE * (args.size / 256.0) ** 2 / 1e3 / peak, 4),
             "last_losses": last,

@@ -52,11 +52,11 @@ constexpr int BN = 128, NTHR = 512;   // the tile height BM is a template parame
 // hide.  The 4 x 2 split is kept (shorter first slab, fewer address registers).
 // Tile 288 x 128 exists for tile-count quantisation: the 66x66 input-gradient domain is 4356 pixels per image = 18 tiles of 256
 // (576 tiles = 2.25 waves on 256 CUs -> 3 rounds) but 16 tiles of 288 (512 tiles -> 2 rounds of 1.125x the work: -25 %).
-constexpr int RMAX = 448;                    // pixels per patch buffer (7 slices of 64)
-constexpr int NSLICE = RMAX / 64;
-constexpr int PATCHB = RMAX * 128;
+// pixels per patch buffer: 7 slices of 64 (maps up to 64 pixels wide: a 256-pixel tile of a 3x3 window spans 6 padded rows), or 9 slices
+// for maps up to 128 wide (512x512 images: 4 padded rows of 130) -- template parameter NS; two buffers of 9 slices are 147 KB of LDS
+constexpr int RMAX = 448, RMAX_WIDE = 576;
 constexpr int STATS_LDS = 8 * 128 * 2 * 4;    // per-wave (sum, sumsq) of up to 128 channels, combined across the pixel-split waves
-constexpr int LDS_BYTES = 2 * PATCHB + 512 + STATS_LDS;
+constexpr int lds_bytes(int ns) { return 2 * ns * 64 * 128 + 512 + STATS_LDS; }
 
 struct TileGeo { int b, m0, n0, P0; };
 
@@ -97,9 +97,10 @@ __device__ __forceinline__ TileGeo tile_geo(const PatchArgs& a, int tau) {
 // moved the fp8 MFMA takes the cycles of the two bf16 MFMAs it replaces: twice the FLOPs per byte, HBM and LDS traffic halved.
 typedef __attribute__((ext_vector_type(8))) int v8i_t;
 typedef __attribute__((ext_vector_type(4))) int v4i_t;
-template <int BM, int WGN, int NT, bool FP8 = false>
-__global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
+template <int BM, int WGN, int NT, bool FP8 = false, int NS = 7>
+__device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
   static_assert(!FP8 || NT == 0, "the fp8 path uses the generic tap loop");
+  constexpr int NSLICE = NS, PATCHB = NS * 64 * 128;
   constexpr int FI = BM / (8 / WGN) / 16, FJ = BN / WGN / 16;   // fragments per wave: FI pixel groups x FJ channel groups
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   char* pbuf = lds;                       // [2][PATCHB]
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
   }
   u32x4_t Wa[FJ], Wb[FJ], Xa[FI], Xb[FI];   // operand fragments of the even / odd k-step of a tap
   // FP8: 32-byte operands of a whole tap (both k-steps), two sets: the tap being multiplied and the next one in flight
-  v8i_t W8[2][FP8 ? FJ : 1], X8[2][FP8 ? FI : 1];
+  v8i_t W8[2][FP8 ? FJ : 1], X8[1][FP8 ? FI : 1];
   auto w_load8 = [&](int n0_tile, int kb, v8i_t (&f)[FP8 ? FJ : 1]) {
     const int base = __builtin_amdgcn_readfirstlane((((n0_tile + wn_u * (16 * FJ)) >> 4) * a.KB + kb) * 1024);
 #pragma unroll
@@ -295,6 +296,10 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
         static_slab(std::integral_constant<int, 1>{}, c + 1);
       }
     } else if constexpr (FP8) {
+      // One k-step = one tap over the whole 128-byte slab row.  Registers are what limits this variant (the bf16 kernels leave 80 per
+      // SIMD lane to the kernels of the other streams; so must this one): weights are double-buffered (L2 latency), the activation
+      // fragments are ONE set that is re-read for the next tap fragment by fragment, each right after the four MFMAs that consume it
+      // (pixel-group-major MFMA order): its LDS latency hides behind the remaining MFMAs of the tap.
       for (int c = 0; c < a.nchunk; ++c) {
         const bool last_chunk = c + 1 == a.nchunk;
         const bool stage_next = !last_chunk || has_next;
@@ -311,21 +316,9 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
             xaddr[i] = (uint32_t)(prow * 128 + ((fg ^ (prow & 7)) << 4));
           }
         };
-        auto x_load8 = [&](v8i_t (&xf)[FP8 ? FI : 1]) {
-#pragma unroll
-          for (int i = 0; i < (FP8 ? FI : 1); ++i) {
-            const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(pb + xaddr[i]), hi = *reinterpret_cast<const u32x4_t*>(pb + (xaddr[i] ^ 64u));
-            xf[i] = __builtin_shufflevector(__builtin_bit_cast(v4i_t, lo), __builtin_bit_cast(v4i_t, hi), 0, 1, 2, 3, 4, 5, 6, 7);
-          }
-        };
-        auto mma8 = [&](const v8i_t (&wf)[FP8 ? FJ : 1], const v8i_t (&xf)[FP8 ? FI : 1], int i0, int i1) {
-#pragma unroll
-          for (int i = 0; i < (FP8 ? FI : 1); ++i)
-            if (i >= i0 && i < i1) {
-#pragma unroll
-              for (int j = 0; j < (FP8 ? FJ : 1); ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], xf[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-            }
+        auto x_read = [&](int i) -> v8i_t {
+          const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(pb + xaddr[i]), hi = *reinterpret_cast<const u32x4_t*>(pb + (xaddr[i] ^ 64u));
+          return __builtin_shufflevector(__builtin_bit_cast(v4i_t, lo), __builtin_bit_cast(v4i_t, hi), 0, 1, 2, 3, 4, 5, 6, 7);
         };
         auto step = [&](auto par_tag, int t) {
           constexpr int P = decltype(par_tag)::value;
@@ -334,30 +327,33 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
           const int nc = last_tap ? (last_chunk ? 0 : c + 1) : c;
           const int nn0 = (last_tap && last_chunk) ? gn.n0 : g.n0;
           const int kb_next = kb_of(nc, nt);
-          const int toff_next = taptab[last_tap ? t : t + 1];
-          __builtin_amdgcn_sched_barrier(0);
-          mma8(W8[P], X8[P], 0, FI / 2);               // waits for this tap's operands (issued one tap ago) land here
+          x_addr(taptab[last_tap ? t : t + 1]);        // after the last tap: a harmless re-read (the next slab is read after the barrier)
           __builtin_amdgcn_sched_barrier(0);
           w_load8(nn0, kb_next, W8[P ^ 1]);            // next tap, else first tap of the next slab / tile
-          x_addr(toff_next);                           // after the last tap: a harmless re-read (the next slab's activations wait for
-          x_load8(X8[P ^ 1]);                          // the barrier and are read at its start); unconditional -> no register copies
-          if (stage_next) {
-            if (sj > 0 && sj <= NSLICE) slab_store(pcur ^ 1, sj - 1, stg);
-            if (sj < NSLICE) stg = slab_load(gs, cs, sj);
-            ++sj;
+#pragma unroll
+          for (int i = 0; i < (FP8 ? FI : 1); ++i) {
+#pragma unroll
+            for (int j = 0; j < (FP8 ? FJ : 1); ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(W8[P][j], X8[0][i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            __builtin_amdgcn_sched_barrier(0);
+            X8[0][i] = x_read(i);
+            if (i == 0 && stage_next) {
+              if (sj > 0 && sj <= NSLICE) slab_store(pcur ^ 1, sj - 1, stg);
+              if (sj < NSLICE) stg = slab_load(gs, cs, sj);
+              ++sj;
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);
-          mma8(W8[P], X8[P], FI / 2, FI);
         };
-        // every slab starts on set 0; the tap loop is unrolled by two and an odd last tap hands the prefetched weights over
         x_addr(taptab[0]);
-        x_load8(X8[0]);
+#pragma unroll
+        for (int i = 0; i < (FP8 ? FI : 1); ++i) X8[0][i] = x_read(i);
         int t = 0;
         for (; t + 1 < a.ntaps; t += 2) {
           step(std::integral_constant<int, 0>{}, t);
           step(std::integral_constant<int, 1>{}, t + 1);
         }
-        if (t < a.ntaps) {
+        if (t < a.ntaps) {     // odd tap count: the prefetched weights change sets
           step(std::integral_constant<int, 0>{}, t);
 #pragma unroll
           for (int j = 0; j < (FP8 ? FJ : 1); ++j) W8[0][j] = W8[1][j];
@@ -552,6 +548,14 @@ __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) {
   }
 }
 
+template <int BM, int WGN, int NT, bool FP8 = false, int NS = 7>
+__global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) { conv_patch_body<BM, WGN, NT, FP8, NS>(a); }
+// the fp8 variants are capped at 216 registers like the bf16 input-gradient kernel: the other streams' kernels (weight-gradient
+// reduction, InstanceNorm passes) keep 80 registers per SIMD lane to run beside them (uncapped, the compiler takes all 256 and the
+// step loses 0.8 ms to the serialisation)
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_num_vgpr(216))) void conv_patch_fp8_kernel(PatchArgs a) { conv_patch_body<256, 2, 0, true, 7>(a); }
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_num_vgpr(216))) void conv_patch_fp8_wide_kernel(PatchArgs a) { conv_patch_body<256, 2, 0, true, 9>(a); }
+
 }  // namespace
 
 // pixels of the contiguous input range a tile of BM output pixels reads (all taps)
@@ -570,11 +574,12 @@ static int patch_tile_rows(const gan_conv_desc* d, bool planning = false) {
   const int M_img = d->Ho * d->Wo, ncu = 256;
   int BM = 0, forced = 0;
   int64_t best = 0;
-  if (!planning && (d->tile_rows == 256 || d->tile_rows == 288) && patch_span(d, d->tile_rows) <= RMAX) return d->tile_rows;
+  if (!planning && (d->tile_rows == 256 || d->tile_rows == 288) && patch_span(d, d->tile_rows) <= (d->tile_rows == 256 ? RMAX_WIDE : RMAX)) return d->tile_rows;
   if (d->dtype == GAN_FP8) return 256;
   if (planning) { const char* e = getenv("GAN_PATCH_BM"); forced = e ? atoi(e) : 0; }
   for (int cand : {256, 288}) {
-    if (patch_span(d, cand) > RMAX || (forced && forced != cand && patch_span(d, forced) <= RMAX)) continue;
+    const int lim = cand == 256 ? RMAX_WIDE : RMAX;      // the 9-slice buffers exist for the 256-row tile only
+    if (patch_span(d, cand) > lim || (forced && forced != cand && patch_span(d, forced) <= (forced == 256 ? RMAX_WIDE : RMAX))) continue;
     const int64_t tiles = (int64_t)d->B * ((M_img + cand - 1) / cand) * ((d->Nst + BN - 1) / BN);
     const int64_t cost = ((tiles + ncu - 1) / ncu) * cand;
     if (!BM || cost < best) { BM = cand; best = cost; }
@@ -592,9 +597,9 @@ extern "C" int gan_conv_patch_ok(const gan_conv_desc* d) {
   const bool fp8 = d->dtype == GAN_FP8;
   const int slots = fp8 ? d->Cin / 2 : d->Cin;             // 2-byte slots per pixel (fp8: two channels per slot)
   if ((d->dtype != GAN_BF16 && !fp8) || slots < 64 || slots % 64 != 0 || d->Nw % BN != 0 || d->Nst % 8 != 0 || d->out_C % 8 != 0) return 0;
-  if (fp8 && (d->mask || !d->w_scale || patch_span(d, 256) > RMAX)) return 0;   // fp8: 256-row tile, plain epilogue
+  if (fp8 && (d->mask || !d->w_scale || patch_span(d, 256) > RMAX_WIDE)) return 0;   // fp8: 256-row tile, plain epilogue
   if (d->max_tapoff <= 0 || d->ntaps < 1) return 0;
-  if (!(patch_span(d, 256) <= RMAX || patch_span(d, 288) <= RMAX)) return 0;
+  if (!(patch_span(d, 256) <= RMAX_WIDE || patch_span(d, 288) <= RMAX)) return 0;
   // tile utilisation: a map of 324 pixels (18x18 input-gradient domain of a 16x16 layer) fills 63 % of two 256-row tiles -- the
   // generic kernel's 128-row tiles waste less there (Basic_GAN at 64x64: +5 % with it)
   const int M_img = d->Ho * d->Wo;
@@ -648,24 +653,27 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   if (hipGetDevice(&dev) != hipSuccess) return gan_set_error(-2, "conv_patch: hipGetDevice failed");
   const uint64_t dev_bit = 1ull << (dev & 63);
   if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
-    if (hipFuncSetAttribute((const void*)conv_patch_kernel<256, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv_patch_kernel<288, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv_patch_kernel<256, 2, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv_patch_kernel<256, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-      return gan_set_error(-2, "conv_patch: cannot raise the dynamic LDS limit to %d bytes", LDS_BYTES);
+    auto raise = [](const void* f, int bytes) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; };
+    if (!raise((const void*)conv_patch_kernel<256, 2, 0>, lds_bytes(7)) || !raise((const void*)conv_patch_kernel<288, 4, 0>, lds_bytes(7)) ||
+        !raise((const void*)conv_patch_kernel<256, 2, 9>, lds_bytes(7)) || !raise((const void*)conv_patch_fp8_kernel, lds_bytes(7)) ||
+        !raise((const void*)conv_patch_kernel<256, 2, 0, false, 9>, lds_bytes(9)) || !raise((const void*)conv_patch_fp8_wide_kernel, lds_bytes(9)))
+      return gan_set_error(-2, "conv_patch: cannot raise the dynamic LDS limit to %d bytes", lds_bytes(9));
     attr_devs.fetch_or(dev_bit, std::memory_order_release);
   }
   // The static 3x3 schedule, 256-row tile only.  Measured (s_memtime): 15.5 k -> 13.0 k cycles per slab, but the denser issue
   // stream clocks lower (2.04 -> 1.88 GHz), so the forward gains 3 % wall (69.5 -> 67.2 us = 1.15 PFLOP/s); on the 288-row tile,
   // whose 9 fragment addresses per tap do not fit in registers, it lost 9 % and is not instantiated.
-  const bool st9 = BM == 256 && d->ntaps == 9 && a.nchunk % 2 == 0 && !static_off;
+  const bool wide = BM == 256 && patch_span(d, 256) > RMAX;      // needs the 9-slice buffers (maps wider than 64 pixels)
+  const bool st9 = BM == 256 && !wide && d->ntaps == 9 && a.nchunk % 2 == 0 && !static_off;
   if (fp8) {
-    hipLaunchKernelGGL((conv_patch_kernel<256, 2, 0, true>), dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
+    if (wide) hipLaunchKernelGGL(conv_patch_fp8_wide_kernel, dim3(grid), dim3(NTHR), lds_bytes(9), s, a);
+    else hipLaunchKernelGGL(conv_patch_fp8_kernel, dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
   } else if (BM == 256) {
-    if (st9) hipLaunchKernelGGL((conv_patch_kernel<256, 2, 9>), dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
-    else hipLaunchKernelGGL((conv_patch_kernel<256, 2, 0>), dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
+    if (wide) hipLaunchKernelGGL((conv_patch_kernel<256, 2, 0, false, 9>), dim3(grid), dim3(NTHR), lds_bytes(9), s, a);
+    else if (st9) hipLaunchKernelGGL((conv_patch_kernel<256, 2, 9>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
+    else hipLaunchKernelGGL((conv_patch_kernel<256, 2, 0>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
   } else {
-    hipLaunchKernelGGL((conv_patch_kernel<288, 4, 0>), dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((conv_patch_kernel<288, 4, 0>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
   }
   if (hipGetLastError() != hipSuccess) return gan_set_error(-2, "conv_patch: launch failed");
   return 0;

@@ -331,12 +331,17 @@ class CutTrainer:
     """
 
     def __init__(self, generator: ResNetGenerator, discriminator: MultiscaleDiscriminator, config: dict, batch_size: int, image_size: int,
-                 device="cuda", amp: Optional[bool] = None, ops=None, world_size: int = 1, process_group=None):
+                 device="cuda", amp: Optional[bool] = None, ops=None, world_size: int = 1, process_group=None, fp8: Optional[bool] = None):
+        """fp8 (default: config['mi355x']['fp8'], else False): the residual blocks' convolutions read e4m3 operand copies in the forward pass
+        and in the input gradient (BASELINE.json configs[4]); needs amp (bf16) -- see nets.GeneratorNet."""
         self.config = config
         self.B, self.S = batch_size, image_size
         self.device = torch.device(device)
         amp = config.get("amp", True) if amp is None else amp
         self.amp = AMPContext(amp)
+        self.fp8 = bool((config.get("mi355x") or {}).get("fp8", False) if fp8 is None else fp8)
+        if self.fp8 and not amp:
+            raise ValueError("fp8 convolutions exist in the bf16 (amp) mode only: fp32 is the parity mode")
         self.ops = ops if ops is not None else HipOps(self.device)
         if hasattr(self.ops, "bind"):
             self.ops.bind()                 # one stream for this trainer's launches and its torch-side copies / events, from now on
@@ -374,7 +379,7 @@ class CutTrainer:
 
         B, S = self.B, self.S
         nb, ngf = generator.n_blocks, generator.ngf
-        self.G = GeneratorNet(self.ctx, self.opt_G.params, self.opt_G.grads, "cut", nb, ngf, need_input_grad=True)
+        self.G = GeneratorNet(self.ctx, self.opt_G.params, self.opt_G.grads, "cut", nb, ngf, need_input_grad=True, fp8=self.fp8)
         self.D = DiscriminatorNet(self.ctxD, self.opt_D.params, self.opt_D.grads, "cut", ndf=discriminator.ndf, n_layers=discriminator.n_layers)
         self.D32 = self.D if self.ctx32 is self.ctxD else DiscriminatorNet(self.ctx32, self.opt_D.params, self.opt_D.grads, "cut",
                                                                           ndf=discriminator.ndf, n_layers=discriminator.n_layers)

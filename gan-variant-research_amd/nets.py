@@ -14,7 +14,7 @@ from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
 
-from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, F32, HALO_REFLECT, HALO_ZERO
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, BF16, F32, FP8, HALO_REFLECT, HALO_ZERO
 from .convplan import ConvLayer
 from .runtime import IN_WS_CHUNKS, Ctx, Program, View, cpad
 
@@ -73,10 +73,15 @@ class GeneratorNet(_Net):
     """9-block ResNet generator of both trainers (CUT: biased convs; Basic_GAN: bias-free but the last)."""
 
     def __init__(self, ctx, params, grads, style="cut", n_blocks=9, ngf=64, in_c=3, out_c=3, need_input_grad=True, reflect=True,
-                 block_act=ACT_RELU):
+                 block_act=ACT_RELU, fp8=False):
         """reflect: `padding_type` 'reflect' (the configs' value) or 'zero'; block_act: the residual blocks' activation (ReLU in the
-        configs, LeakyReLU(0.2) for activation='leaky_relu', generator_resnet_attn.py:60-66)."""
+        configs, LeakyReLU(0.2) for activation='leaky_relu', generator_resnet_attn.py:60-66).
+        fp8: the residual blocks' 3x3 convolutions (generator_resnet_attn.py:33,48 -- 88 % of the generator's FLOPs) read e4m3 copies of
+        their operands in the forward pass and in the input gradient (BASELINE.json configs[4]); weight gradients, InstanceNorm, the
+        first / last layers and everything stored stay bf16 / fp32.  bf16 mode with reflect padding only."""
         super().__init__(ctx, params, grads)
+        self.fp8 = bool(fp8)
+        assert not self.fp8 or (ctx.dtype == BF16 and reflect and 4 * ngf >= 128 and (4 * ngf) % 128 == 0), "fp8 blocks: bf16 mode, reflect padding, >= 128 channels"
         self.style, self.n_blocks, self.ngf, self.in_c, self.out_c = style, n_blocks, ngf, in_c, out_c
         self.reflect, self.block_act = reflect, block_act
         self.pad_mode = HALO_REFLECT if reflect else HALO_ZERO
@@ -126,7 +131,20 @@ class GPass:
                 self.raw.append(v(B, h, w, c, 0))
                 self.stats.append(ctx.f32(B * c * 2))
         self.mid = [v(B, H // 4, W // 4, 4 * g, 1) for _ in range(min(nb, max(0, self.last - 2)))]  # T_k: reflect halo 1
+        if net.fp8:      # e4m3 copies of the residual convolutions' inputs (block input, T_k); gradients: see bwd_program
+            self.in8 = [v(B, H // 4, W // 4, 4 * g, 1, dtype=FP8) for _ in self.mid]
+            self.mid8 = [v(B, H // 4, W // 4, 4 * g, 1, dtype=FP8) for _ in self.mid]
         self.img = v(B, H, W, cpad(net.out_c), 0) if self.full else None
+
+    def _fp8_grad_bufs(self, B, h, w, c):
+        """e4m3 copy of a residual convolution's output gradient (zero halo 2) with its per-image amax / scale: one set per network and
+        shape (producer and consumer are neighbours on the main stream)."""
+        net = self.net
+        key = ("fp8g", B, h, w, c)
+        bufs = net._gbufs.get(key)
+        if bufs is None:
+            bufs = net._gbufs[key] = (net.ctx.view(B, h, w, c, 2, dtype=FP8), net.ctx.f32(B), net.ctx.f32(B, 1.0))
+        return bufs
 
     def halo_mode(self, i: int) -> int:
         nb = self.net.n_blocks
@@ -176,9 +194,16 @@ class GPass:
             ca, cb = net.c_blk[k]
             ra, rb = self.raw[i]
             sa, sb = self.stats[i]
-            prog.add(ca.fwd(self.acts[i - 1], ra, stats_ws=net.in_ws(self.B, ra.C)))
-            norm(i, ra, sa, net.block_act, out=self.mid[k], conv=ca)
-            prog.add(cb.fwd(self.mid[k], rb, stats_ws=net.in_ws(self.B, rb.C)))
+            if net.fp8:
+                prog.add(ops.quantize_fp8(self.acts[i - 1], self.in8[k]))
+                prog.add(ca.fwd8(self.in8[k], ra, stats_ws=net.in_ws(self.B, ra.C)))
+                norm(i, ra, sa, net.block_act, out=self.mid[k], conv=ca)
+                prog.add(ops.quantize_fp8(self.mid[k], self.mid8[k]))
+                prog.add(cb.fwd8(self.mid8[k], rb, stats_ws=net.in_ws(self.B, rb.C)))
+            else:
+                prog.add(ca.fwd(self.acts[i - 1], ra, stats_ws=net.in_ws(self.B, ra.C)))
+                norm(i, ra, sa, net.block_act, out=self.mid[k], conv=ca)
+                prog.add(cb.fwd(self.mid[k], rb, stats_ws=net.in_ws(self.B, rb.C)))
             norm(i, rb, sb, ACT_NONE, residual=self.acts[i - 1], conv=cb)
         for j in range(2):
             i = 3 + nb + j
@@ -236,9 +261,19 @@ class GPass:
         if not hasattr(self, "_bias_parts"):
             self._bias_parts = {}
 
-        def inbwd(raw, stats, act, gy, fold, dx, conv=None):
-            """InstanceNorm backward; with `conv`, its bias gradient (column sums of dx) comes out of the same pass."""
-            if conv is not None and conv.grad_b is not None and defer:
+        def inbwd(raw, stats, act, gy, fold, dx, conv=None, amax=None):
+            """InstanceNorm backward; with `conv`, its bias gradient (column sums of dx) comes out of the same pass; with `amax`, max|dx|
+            per image too (the scale of dx's e4m3 copy)."""
+            if amax is not None:
+                part = None
+                if conv is not None and conv.grad_b is not None:
+                    nparts = ops.in_bwd_bias_parts(raw)
+                    part = self._bias_parts.get(id(conv))
+                    if part is None:
+                        part = self._bias_parts[id(conv)] = ctx.f32(nparts * raw.C)
+                    bias_items.append((part, nparts, raw.C, conv.grad_b, conv.cout, acc))
+                prog.add(ops.in_bwd_amax(raw, stats, act, gy, fold, dx, net.in_ws(B, raw.C), part, amax))
+            elif conv is not None and conv.grad_b is not None and defer:
                 nparts = ops.in_bwd_bias_parts(raw)
                 part = self._bias_parts.get(id(conv))
                 if part is None:
@@ -287,16 +322,30 @@ class GPass:
             c4, h4, w4 = ra.C, ra.H, ra.W
             dyb = net.gbuf(f"dy_blk_b{k % 2}", B, h4, w4, c4, 2)   # two sets, alternating: the side stream reads them one block late
             before_write(dyb)
-            inbwd(rb, sb, ACT_NONE, g_cur, False, dyb, cb)
-            wgrad_side(cb, self.mid[k], dyb, False)
             g_mid = net.gbuf("g_blk_p", B, h4, w4, c4, 1)
-            prog.add(cb.dgrad(dyb, g_mid, padded_domain=rf))
+            if net.fp8:
+                # input gradients on e4m3 operands: the norm backward leaves max|dY| per image, the copy is scaled by it
+                dy8, am8, sc8 = self._fp8_grad_bufs(B, h4, w4, c4)
+                inbwd(rb, sb, ACT_NONE, g_cur, False, dyb, cb, amax=am8)
+                wgrad_side(cb, self.mid[k], dyb, False)
+                prog.add(ops.quantize_fp8(dyb, dy8, am8, sc8))
+                prog.add(cb.dgrad8(dy8, g_mid, sc8, padded_domain=rf))
+            else:
+                inbwd(rb, sb, ACT_NONE, g_cur, False, dyb, cb)
+                wgrad_side(cb, self.mid[k], dyb, False)
+                prog.add(cb.dgrad(dyb, g_mid, padded_domain=rf))
             dya = net.gbuf(f"dy_blk_a{k % 2}", B, h4, w4, c4, 2)
             before_write(dya)
-            inbwd(ra, sa, net.block_act, g_mid, rf, dya, ca)
-            wgrad_side(ca, self.acts[i - 1], dya, False)
             g_in_p = net.gbuf("g_blk_p", B, h4, w4, c4, 1)
-            prog.add(ca.dgrad(dya, g_in_p, padded_domain=rf))
+            if net.fp8:
+                inbwd(ra, sa, net.block_act, g_mid, rf, dya, ca, amax=am8)
+                wgrad_side(ca, self.acts[i - 1], dya, False)
+                prog.add(ops.quantize_fp8(dya, dy8, am8, sc8))
+                prog.add(ca.dgrad8(dy8, g_in_p, sc8, padded_domain=rf))
+            else:
+                inbwd(ra, sa, net.block_act, g_mid, rf, dya, ca)
+                wgrad_side(ca, self.acts[i - 1], dya, False)
+                prog.add(ca.dgrad(dya, g_in_p, padded_domain=rf))
             g_next = net.gbuf(f"g_res{k % 2}", B, h4, w4, c4, 0)
             prog.add(ops.fold_add(g_cur, g_in_p, rf, g_next))
             g_cur = g_next

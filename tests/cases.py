@@ -128,13 +128,13 @@ def small_config():
 
 
 
-def run_cut_steps(device, ops, use_aug, amp=False, S=32, B=2, nsteps=2, tol0=2e-4, tol1=2e-3, atol1=2e-4, ptol=4.5e-4):
+def run_cut_steps(device, ops, use_aug, amp=False, S=32, B=2, nsteps=2, tol0=2e-4, tol1=2e-3, atol1=2e-4, ptol=4.5e-4, fp8=False):
     torch.set_num_threads(4)
     cfg = small_config()
     cfg["diffaugment"]["enable"] = use_aug
     C.set_seed(42)
     gen, disc = C.build_models(cfg, "cpu")
-    tr = C.CutTrainer(gen, disc, cfg, B, S, device=device, amp=amp, ops=ops)
+    tr = C.CutTrainer(gen, disc, cfg, B, S, device=device, amp=amp, ops=ops, fp8=fp8)
     cut_ref.set_seed(42)
     gp, dp = cut_ref.init_generator(), cut_ref.init_discriminator()
     og, od = cut_ref.AdamState(gp), cut_ref.AdamState(dp)

@@ -115,7 +115,7 @@ class EmuOps:
         rows = min(256, m_img)
         wraps = (rows - 1) // c.Wo + 1
         jump = max(0, c.x.Wp * c.in_sy - c.Wo * c.in_sx)
-        if (rows - 1) * c.in_sx + wraps * jump + c.max_tapoff // c.Cin + 1 > 448:
+        if (rows - 1) * c.in_sx + wraps * jump + c.max_tapoff // c.Cin + 1 > 576:     # the 256-row tile's 9-slice buffers (maps up to 128 wide)
             return False
         if fp8 or c.B * (-(-m_img // 256)) <= 128:
             return True

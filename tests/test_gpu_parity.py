@@ -455,6 +455,14 @@ def test_fp8_conv_path_hip(H):
         assert float((gotd[bi] - emud[bi]).abs().max()) < 2e-2 * float(rmsd[bi])
 
 
+def test_cut_train_step_fp8_vs_oracle():
+    """BASELINE.json configs[4] at test size: the CUT step with e4m3 operand copies for the residual convolutions (forward and input
+    gradient) at 64x64 against the fp32 oracle.  Stated fp8 tolerance: step-0 losses within 8 %, generated image within 0.3 max / 0.06 rms."""
+    tr, img, ref_img = cases.run_cut_steps(DEV, HipOps(torch.device(DEV)), True, amp=True, S=64, B=2, nsteps=1, tol0=8e-2, ptol=4.5e-4, fp8=True)
+    assert tr.fp8
+    assert float((img - ref_img).abs().max()) < 0.3 and float((img - ref_img).pow(2).mean().sqrt()) < 0.06
+
+
 def test_ops_library_hip(monkeypatch):
     """torch.ops.mi355x_gan.* on the kernels: the generator and discriminator assembled layer by layer from the op-level drop-in modules
     reproduce the reference's own outputs (golden) and the oracle's gradients; the fused clip+Adam+EMA op matches torch.optim.Adam."""
