@@ -87,6 +87,7 @@ PROTOTYPES = {
     "gan_in_partial_count": (C.c_int, [PV]),
     "gan_in_partial": (C.c_int, [PV, vp, vp]),
     "gan_in_apply_parts": (C.c_int, [PV, vp, C.c_int, f32, vp, C.c_int, PV, PV, C.c_int, vp]),
+    "gan_in_apply_parts_fp8": (C.c_int, [PV, vp, C.c_int, f32, vp, C.c_int, PV, PV, PV, C.c_int, vp]),
     "gan_in_bwd": (C.c_int, [PV, vp, C.c_int, PV, C.c_int, PV, PV, vp, vp]),
     "gan_in_bwd_bias": (C.c_int, [PV, vp, C.c_int, PV, C.c_int, PV, PV, vp, vp, C.c_int, C.c_int, vp]),
     "gan_fold_add": (C.c_int, [PV, PV, C.c_int, PV, vp]),

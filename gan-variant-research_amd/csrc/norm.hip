@@ -149,9 +149,11 @@ __device__ __forceinline__ void block_sums(const float* __restrict__ parts, int 
 // iterates the padded domain when halo_mode == REFLECT, else the interior.  Statistics: `stats` (mean, rstd) as given, or -- when
 // `parts` is set -- computed here from the partial sums (sum, sum of squares) and written to `stats` by the image's first block
 // (the backward reads them).
+// y8 (optional): an e4m3 copy of y with the same geometry (unit scale, clamped to +-448) written by the same pass -- the operand of the
+// next convolution on the fp8 path, at the price of one extra 8-byte store per chunk instead of a separate quantisation pass.
 template <typename T, int UNR>
 __global__ __launch_bounds__(NTHR) void in_apply_kernel(DView x, float* __restrict__ stats, const float* __restrict__ parts, int nparts, float eps,
-                                                       int act, DView res, int has_res, DView y, int halo_mode, int nblk) {
+                                                       int act, DView res, int has_res, DView y, int halo_mode, int nblk, uint8_t* __restrict__ y8 = nullptr) {
   constexpr int N = Chunk<T>::N;
   Lanes<T> L(x.C);
   const int b = blockIdx.y, cofs = L.cl * N;
@@ -210,6 +212,13 @@ __global__ __launch_bounds__(NTHR) void in_apply_kernel(DView x, float* __restri
           for (int e = 0; e < N; ++e) v[e] += r[e];
         }
         Chunk<T>::store(yp + oo[u] + cofs, v);
+        if (y8) {
+          uint32_t q[N / 4];
+#pragma unroll
+          for (int k = 0; k < N / 4; ++k) q[k] = f2e4m3x4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+          if (N == 8) *reinterpret_cast<u32x2_t*>(y8 + oo[u] + cofs) = u32x2_t{q[0], q[N / 4 - 1]};
+          else *reinterpret_cast<uint32_t*>(y8 + oo[u] + cofs) = q[0];
+        }
       }
     }
   }
@@ -741,7 +750,7 @@ extern "C" int gan_in_apply(const gan_view* x, const float* stats, int act, cons
   const int nblk = nblocks_for(DH * DW, lanes_of(x));
   DView dx = to_dview(x), dy = to_dview(y), dr = residual ? to_dview(residual) : null_dview();
   GAN_DISPATCH_NORM_FWD(x->dtype, hipLaunchKernelGGL((in_apply_kernel<T, U>), dim3(nblk, x->B), dim3(NTHR), 0, (hipStream_t)stream, dx,
-                                                  const_cast<float*>(stats), (const float*)nullptr, 0, 0.f, act, dr, residual ? 1 : 0, dy, halo_mode, nblk);)
+                                                  const_cast<float*>(stats), (const float*)nullptr, 0, 0.f, act, dr, residual ? 1 : 0, dy, halo_mode, nblk, (uint8_t*)nullptr);)
   GAN_LAUNCH_CHECK();
   return 0;
 }
@@ -765,8 +774,22 @@ extern "C" int gan_in_partial(const gan_view* x, float* parts, void* stream) {
 // gan_in_apply with the statistics taken from per-chunk partials (gan_in_partial, or a convolution epilogue's gan_conv_desc.stats):
 // every block sums the nparts (<= 16) partial pairs of its image itself, so no finalize launch precedes the pass; the image's first
 // block also writes (mean, rstd) to `stats` for the backward pass.
+static int in_apply_parts_impl(const gan_view* x, const float* parts, int nparts, float eps, float* stats, int act, const gan_view* residual,
+                               const gan_view* y, const gan_view* y8, int halo_mode, void* stream);
 extern "C" int gan_in_apply_parts(const gan_view* x, const float* parts, int nparts, float eps, float* stats, int act, const gan_view* residual,
                                   const gan_view* y, int halo_mode, void* stream) {
+  return in_apply_parts_impl(x, parts, nparts, eps, stats, act, residual, y, nullptr, halo_mode, stream);
+}
+// the same pass writing, besides y, an e4m3 copy y8 of it (GAN_FP8 view of y's geometry; unit scale): gan_quantize_fp8(y, y8) for free
+extern "C" int gan_in_apply_parts_fp8(const gan_view* x, const float* parts, int nparts, float eps, float* stats, int act, const gan_view* residual,
+                                      const gan_view* y, const gan_view* y8, int halo_mode, void* stream) {
+  if (gan_check_view(y8, "in_apply_parts_fp8.y8") || gan_check_view(y, "in_apply_parts_fp8.y")) return -1;
+  GAN_CHECK(y8->dtype == GAN_FP8 && y8->B == y->B && y8->Hp == y->Hp && y8->Wp == y->Wp && y8->C == y->C && y8->y0 == y->y0 && y8->x0 == y->x0,
+            "in_apply_parts_fp8: y8 must be an fp8 view of y's geometry");
+  return in_apply_parts_impl(x, parts, nparts, eps, stats, act, residual, y, y8, halo_mode, stream);
+}
+static int in_apply_parts_impl(const gan_view* x, const float* parts, int nparts, float eps, float* stats, int act, const gan_view* residual,
+                               const gan_view* y, const gan_view* y8, int halo_mode, void* stream) {
   VCHK(x, "in_apply_parts.x"); VCHK(y, "in_apply_parts.y");
   if (check_lanes(x, "in_apply_parts")) return -1;
   SAME_SHAPE(x, y, "in_apply_parts(x,y)");
@@ -779,8 +802,9 @@ extern "C" int gan_in_apply_parts(const gan_view* x, const float* parts, int npa
   const int DH = halo_mode == GAN_HALO_REFLECT ? y->H + 2 * y->y0 : y->H, DW = halo_mode == GAN_HALO_REFLECT ? y->W + 2 * y->x0 : y->W;
   const int nblk = nblocks_for(DH * DW, lanes_of(x));
   DView dx = to_dview(x), dy = to_dview(y), dr = residual ? to_dview(residual) : null_dview();
+  uint8_t* p8 = y8 ? (uint8_t*)y8->ptr : nullptr;
   GAN_DISPATCH_NORM_FWD(x->dtype, hipLaunchKernelGGL((in_apply_kernel<T, U>), dim3(nblk, x->B), dim3(NTHR), 0, (hipStream_t)stream, dx, stats, parts, nparts,
-                                                  eps, act, dr, residual ? 1 : 0, dy, halo_mode, nblk);)
+                                                  eps, act, dr, residual ? 1 : 0, dy, halo_mode, nblk, p8);)
   GAN_LAUNCH_CHECK();
   return 0;
 }

@@ -16,6 +16,7 @@
 //    shifts need their own (precomputed) swizzled address -> ~1 vector ALU op per transposed read.
 //  * 8 waves = 2 (n) x 4 (c); a wave owns 4 n-tiles x 1 c-tile x 9 taps = 36 accumulator tiles (144 registers).
 #include <stdlib.h>
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -26,6 +27,11 @@ constexpr int RX = 320;            // x window rows (pixels incl. pitch padding)
 constexpr int GT_BYTES = KM * 256, XP_BYTES = RX * 128, STAGE_BYTES = GT_BYTES + XP_BYTES;
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;
 constexpr int NT = 9;
+// RING variant (maps exactly KM = 128 pixels wide: the residual layers of 512x512 images): a stage is ONE image row, whose window
+// (3 padded rows of 136 pixels) would not fit twice; consecutive stages share two of their three rows, so the rows live in a ring of
+// four slots (image row y -> slot y & 3) and every stage fetches only its newest row -- a third of the window traffic, 135 KB of LDS.
+constexpr int RING_SLOTS = 4, RING_PITCH = 136;
+constexpr int LDS_BYTES_RING = 2 * GT_BYTES + RING_SLOTS * RING_PITCH * 128;
 
 struct WpArgs {
   const char* x; const char* g; float* part;
@@ -41,6 +47,7 @@ __device__ __forceinline__ void glds16q(const char* gbase, uint32_t goff, char* 
                                    (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
+template <bool RING>
 __global__ __launch_bounds__(512) void wgrad_patch_kernel(WpArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -65,8 +72,23 @@ __global__ __launch_bounds__(512) void wgrad_patch_kernel(WpArgs a) {
   const uint32_t xsrc = (uint32_t)((c0 + ((((xp >> 1) ^ ((xr >> 1) & 3)) << 1 | (xp & 1)) << 3)) * 2);
   const uint32_t x_pixb = (uint32_t)a.Cx * 2u, g_pixb = (uint32_t)a.g_C * 2u;
 
+  char* const ring = lds + 2 * GT_BYTES;                 // RING: [RING_SLOTS][pitch][128 B] behind the two g tiles
+  const uint32_t ring_rowb = (uint32_t)(a.pitch * 128);
+  auto load_row = [&](int iy) {                          // RING: one padded image row -> its slot
+    char* slot = ring + (uint32_t)(iy & (RING_SLOTS - 1)) * ring_rowb;
+    const int iyc = iy < a.x_Hp ? iy : a.x_Hp - 1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int row = xr + 64 * i;
+      if (row < a.pitch) {                                 // pitch = 136: the third instruction runs in wave 0 only (rows 128..135)
+        int ix = row + a.x_x0;
+        ix = ix < a.x_Wp ? ix : a.x_Wp - 1;
+        glds16q(a.x, (uint32_t)((b * a.x_Hp + iyc) * a.x_Wp + ix) * x_pixb + xsrc, slot + wave * 1024 + i * 8192);
+      }
+    }
+  };
   auto stage = [&](int st, int buf) {
-    char* gt = lds + buf * STAGE_BYTES;
+    char* gt = lds + buf * (RING ? GT_BYTES : STAGE_BYTES);
     char* xw = gt + GT_BYTES;
     const int m0 = m_begin + st * KM, ho0 = m0 >> a.lgWo;
 #pragma unroll
@@ -76,6 +98,7 @@ __global__ __launch_bounds__(512) void wgrad_patch_kernel(WpArgs a) {
       const int ho = m >> a.lgWo, wo = m & (a.Wo - 1);
       glds16q(a.g, (uint32_t)((b * a.g_Hp + ho + a.g_y0) * a.g_Wp + wo + a.g_x0) * g_pixb + gsrc, gt + wave * 1024 + i * 8192);
     }
+    if constexpr (RING) { load_row(ho0 + 2 + a.x_y0); return; }     // the newest of the stage's three rows
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const int row = xr + 64 * i;                      // window row = image row wr, column wcol
@@ -115,12 +138,19 @@ __global__ __launch_bounds__(512) void wgrad_patch_kernel(WpArgs a) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (RING) { const int iy0 = (m_begin >> a.lgWo) + a.x_y0; load_row(iy0); load_row(iy0 + 1); }
   stage(0, 0);
   for (int st = 0; st < nstage; ++st) {
     __syncthreads();   // stage st landed (LDS-DMA drained + barrier); everyone is done with the other buffer
-    char* gt = lds + (st & 1) * STAGE_BYTES;
-    const char* xw = gt + GT_BYTES;
+    char* gt = lds + (st & 1) * (RING ? GT_BYTES : STAGE_BYTES);
+    const char* xw = RING ? ring : gt + GT_BYTES;
     const int m0 = m_begin + st * KM;
+    uint32_t so[3] = {0u, 0u, 0u};                        // RING: byte offset of the slot of tap row dy
+    if constexpr (RING) {
+      const int iy0 = (m0 >> a.lgWo) + a.x_y0;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) so[dy] = (uint32_t)((iy0 + dy) & (RING_SLOTS - 1)) * ring_rowb;
+    }
     if (m0 + KM > m_end) {   // tail: pixels past the split end must not contribute -> zero their g rows
       for (int c = tid; c < KM * 16; c += 512)
         if (m0 + (c >> 4) >= m_end) *reinterpret_cast<u32x4_t*>(gt + c * 16) = u32x4_t{0, 0, 0, 0};
@@ -137,7 +167,7 @@ __global__ __launch_bounds__(512) void wgrad_patch_kernel(WpArgs a) {
       for (int h = 0; h < 2; ++h) {
         const int ku = ks * 32 + 16 * h;                                                    // wave-uniform part of the pixel index
         const uint32_t goff = (uint32_t)(ku * 256);
-        const uint32_t xoff = (uint32_t)(((ku >> a.lgWo) * a.pitch + (ku & (a.Wo - 1))) * 128);
+        const uint32_t xoff = RING ? (uint32_t)(ku * 128) : (uint32_t)(((ku >> a.lgWo) * a.pitch + (ku & (a.Wo - 1))) * 128);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           gf[i][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(gt + gbase[i] + goff));
@@ -154,7 +184,7 @@ __global__ __launch_bounds__(512) void wgrad_patch_kernel(WpArgs a) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
           xf[t % 3][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4_t*)(xw + xh[h][t % 3] + (uint32_t)(t / 3) * rowb));
+              (__attribute__((address_space(3))) s16x4_t*)(xw + xh[h][t % 3] + (RING ? so[t / 3] : (uint32_t)(t / 3) * rowb)));
       };
       x_read(0);
       x_read(1);
@@ -201,7 +231,7 @@ extern "C" int gan_wgrad_patch_splits(const gan_wgrad_desc* d) {
   // generic kernel, measured).  Require at least 8 stages per split at the split count this kernel would use.
   if (HoWo < 8 * KM && d->B > 64) return 0;
   const int pitch = (d->Wo + 2 + 7) / 8 * 8, nrows = KM / d->Wo + 2;
-  if (nrows * pitch > RX) return 0;
+  if (nrows * pitch > RX && !(d->Wo == KM && pitch == RING_PITCH)) return 0;     // 128-wide maps: the row-ring variant
   const int blocks_per_split = (d->N / NB) * (d->Cx / CB);
   int spi = (256 + d->B * blocks_per_split - 1) / (d->B * blocks_per_split);   // ~one block per CU
   const int max_spi = HoWo / (2 * KM) > 0 ? HoWo / (2 * KM) : 1;
@@ -224,13 +254,18 @@ int gan_wgrad_patch_launch(const gan_wgrad_desc* d, hipStream_t s) {
   a.x_Hp = d->x_Hp; a.x_Wp = d->x_Wp; a.x_y0 = d->x_y0; a.x_x0 = d->x_x0;
   a.g_Hp = d->g_Hp; a.g_Wp = d->g_Wp; a.g_C = d->g_C; a.g_y0 = d->g_y0; a.g_x0 = d->g_x0;
   a.NBLK = d->N / NB; a.CBLK = d->Cx / CB;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)wgrad_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+  static std::atomic<uint64_t> attr_devs{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return gan_set_error(-2, "wgrad_patch: hipGetDevice failed");
+  const uint64_t dev_bit = 1ull << (dev & 63);
+  if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
+    if (hipFuncSetAttribute((const void*)wgrad_patch_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)wgrad_patch_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_RING) != hipSuccess)
       return gan_set_error(-2, "wgrad_patch: cannot raise the dynamic LDS limit to %d bytes", LDS_BYTES);
-    attr_set = true;
+    attr_devs.fetch_or(dev_bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL(wgrad_patch_kernel, dim3(a.NBLK * a.CBLK * d->nsplit), dim3(512), LDS_BYTES, s, a);
+  if (a.nrows * a.pitch > RX) hipLaunchKernelGGL(wgrad_patch_kernel<true>, dim3(a.NBLK * a.CBLK * d->nsplit), dim3(512), LDS_BYTES_RING, s, a);
+  else hipLaunchKernelGGL(wgrad_patch_kernel<false>, dim3(a.NBLK * a.CBLK * d->nsplit), dim3(512), LDS_BYTES, s, a);
   if (hipGetLastError() != hipSuccess) return gan_set_error(-2, "wgrad_patch: launch failed");
   return 0;
 }

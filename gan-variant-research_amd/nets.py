@@ -162,23 +162,25 @@ class GPass:
         else:
             prog.add(ops.nchw_to_view(src, net.in_c, self.x0, net.pad_mode))
 
-        def norm(i, raw, stats, act, residual=None, out=None, conv=None):
+        def norm(i, raw, stats, act, residual=None, out=None, conv=None, out8=None):
             out = self.acts[i] if out is None else out
             halo = self.halo_mode(i) if out is self.acts[i] else net.pad_mode
             ws = net.in_ws(self.B, raw.C)
             fused = not os.environ.get("GAN_NO_FUSED_FINALIZE")
             if conv is not None and conv.stats_parts:     # the convolution's epilogue already wrote per-tile (sum, sum of squares)
                 if fused and conv.stats_parts <= 16:          # few tiles: the apply pass adds them up itself (no statistics launch at all)
-                    prog.add(ops.in_apply_parts(raw, ws, conv.stats_parts, IN_EPS, stats, act, residual, out, halo))
+                    prog.add(ops.in_apply_parts(raw, ws, conv.stats_parts, IN_EPS, stats, act, residual, out, halo, out8))
                     return
                 prog.add(ops.in_stats_from_parts(ws, conv.stats_parts, self.B, raw.C, raw.H * raw.W, IN_EPS, stats))
             elif fused:
                 prog.add(ops.in_partial(raw, ws))
-                prog.add(ops.in_apply_parts(raw, ws, ops.in_partial_count(raw), IN_EPS, stats, act, residual, out, halo))
+                prog.add(ops.in_apply_parts(raw, ws, ops.in_partial_count(raw), IN_EPS, stats, act, residual, out, halo, out8))
                 return
             else:
                 prog.add(ops.in_stats(raw, IN_EPS, stats, ws))
             prog.add(ops.in_apply(raw, stats, act, residual, out, halo))
+            if out8 is not None:
+                prog.add(ops.quantize_fp8(out, out8))
 
         prog.add(net.c_init.fwd(self.x0, self.raw[0], stats_ws=net.in_ws(self.B, self.raw[0].C)))
         norm(0, self.raw[0], self.stats[0], ACT_RELU, conv=net.c_init)
@@ -186,7 +188,7 @@ class GPass:
             if i > self.last:
                 return prog
             prog.add(net.c_down[i - 1].fwd(self.acts[i - 1], self.raw[i]))
-            norm(i, self.raw[i], self.stats[i], ACT_RELU)
+            norm(i, self.raw[i], self.stats[i], ACT_RELU, out8=self.in8[0] if (net.fp8 and i == 2 and self.last > 2) else None)
         for k in range(nb):
             i = 3 + k
             if i > self.last:
@@ -194,16 +196,16 @@ class GPass:
             ca, cb = net.c_blk[k]
             ra, rb = self.raw[i]
             sa, sb = self.stats[i]
-            if net.fp8:
-                prog.add(ops.quantize_fp8(self.acts[i - 1], self.in8[k]))
+            if net.fp8:      # the e4m3 operand copies come out of the InstanceNorm passes that produce the bf16 tensors
                 prog.add(ca.fwd8(self.in8[k], ra, stats_ws=net.in_ws(self.B, ra.C)))
-                norm(i, ra, sa, net.block_act, out=self.mid[k], conv=ca)
-                prog.add(ops.quantize_fp8(self.mid[k], self.mid8[k]))
+                norm(i, ra, sa, net.block_act, out=self.mid[k], conv=ca, out8=self.mid8[k])
                 prog.add(cb.fwd8(self.mid8[k], rb, stats_ws=net.in_ws(self.B, rb.C)))
-            else:
-                prog.add(ca.fwd(self.acts[i - 1], ra, stats_ws=net.in_ws(self.B, ra.C)))
-                norm(i, ra, sa, net.block_act, out=self.mid[k], conv=ca)
-                prog.add(cb.fwd(self.mid[k], rb, stats_ws=net.in_ws(self.B, rb.C)))
+                nxt8 = self.in8[k + 1] if (k + 1 < nb and i + 1 <= self.last) else None
+                norm(i, rb, sb, ACT_NONE, residual=self.acts[i - 1], conv=cb, out8=nxt8)
+                continue
+            prog.add(ca.fwd(self.acts[i - 1], ra, stats_ws=net.in_ws(self.B, ra.C)))
+            norm(i, ra, sa, net.block_act, out=self.mid[k], conv=ca)
+            prog.add(cb.fwd(self.mid[k], rb, stats_ws=net.in_ws(self.B, rb.C)))
             norm(i, rb, sb, ACT_NONE, residual=self.acts[i - 1], conv=cb)
         for j in range(2):
             i = 3 + nb + j

@@ -416,9 +416,14 @@ class HipOps:
         assert parts.dtype == torch.float32 and parts.numel() >= x.B * self.in_partial_count(x) * x.C * 2
         return self._call("gan_in_partial", self._v(x), self._p(parts), self._s())
 
-    def in_apply_parts(self, x: View, parts, nparts, eps, stats, act, residual: Optional[View], y: View, halo_mode) -> Op:
-        """InstanceNorm apply with the statistics summed from `nparts` (<= 16) partial pairs per image inside the pass (no finalize launch)."""
+    def in_apply_parts(self, x: View, parts, nparts, eps, stats, act, residual: Optional[View], y: View, halo_mode, y8: Optional[View] = None) -> Op:
+        """InstanceNorm apply with the statistics summed from `nparts` (<= 16) partial pairs per image inside the pass (no finalize launch).
+        y8: an e4m3 view of y's geometry that receives a copy of y in the same pass (fp8 path)."""
         assert 1 <= nparts <= 16 and parts.numel() >= x.B * nparts * x.C * 2 and stats.numel() >= x.B * x.C * 2
+        if y8 is not None:
+            assert y8.dtype == FP8 and (y8.B, y8.Hp, y8.Wp, y8.C, y8.halo) == (y.B, y.Hp, y.Wp, y.C, y.halo)
+            return self._hbm(self._call("gan_in_apply_parts_fp8", self._v(x), self._p(parts), nparts, C.c_float(eps), self._p(stats), act, self._v(residual),
+                                        self._v(y), self._v(y8), halo_mode, self._s()), x, 2 + (residual is not None))
         return self._hbm(self._call("gan_in_apply_parts", self._v(x), self._p(parts), nparts, C.c_float(eps), self._p(stats), act, self._v(residual),
                                     self._v(y), halo_mode, self._s()), x, 2 + (residual is not None))
 

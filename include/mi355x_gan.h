@@ -172,6 +172,10 @@ int gan_in_partial_count(const gan_view* x);
 int gan_in_partial(const gan_view* x, float* parts, void* stream);
 int gan_in_apply_parts(const gan_view* x, const float* parts, int nparts, float eps, float* stats, int act, const gan_view* residual,
                        const gan_view* y, int halo_mode, void* stream);
+/* gan_in_apply_parts that also writes y8, an e4m3 copy of y (GAN_FP8 view of y's geometry, unit scale, halo included): the operand of the
+ * next convolution on the fp8 path without a separate gan_quantize_fp8 pass */
+int gan_in_apply_parts_fp8(const gan_view* x, const float* parts, int nparts, float eps, float* stats, int act, const gan_view* residual,
+                           const gan_view* y, const gan_view* y8, int halo_mode, void* stream);
 /* backward: g = (fold of `gy` over its reflect halo if fold) [+ g2], masked by act'(xhat) (relu / lrelu);
  * dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) written to the interior of `dx` (halo untouched).
  * ws: fp32 >= B*96*C*2 + B*C*2 floats (gan_in_stats: B*96*C*2). */

@@ -44,6 +44,8 @@ GEOMS = [  # cin, cout, k, s, p, transposed, H, reflect
     # the 64 <-> 3 channel 7x7 layers on multi-tile images with ragged edges (7x7 window kernel: forward of 64->3, input gradient of 3->64)
     (64, 3, 7, 1, 3, False, 37, True),
     (3, 64, 7, 1, 3, False, 21, True),
+    # 128-pixel-wide maps (the residual layers of 512x512 images): 9-slice range-patch buffers, row-ring weight gradient
+    (128, 128, 3, 1, 1, False, 128, True),
 ]
 
 

@@ -150,14 +150,20 @@ class EmuOps:
             parts[:x.B * x.C * 2].view(x.B, 1, x.C, 2).copy_(torch.stack([v.sum((1, 2)), (v * v).sum((1, 2))], -1).unsqueeze(1).float())
         return op
 
-    def in_apply_parts(self, x, parts, nparts, eps, stats, act, residual, y, halo_mode):
-        """Statement of gan_in_apply_parts: gan_in_stats_from_parts followed by gan_in_apply."""
+    def in_apply_parts(self, x, parts, nparts, eps, stats, act, residual, y, halo_mode, y8=None):
+        """Statement of gan_in_apply_parts(_fp8): gan_in_stats_from_parts, gan_in_apply and (y8) an e4m3 copy of the fp32 result."""
         a = self.in_stats_from_parts(parts, nparts, x.B, x.C, x.H * x.W, eps, stats)
         b = self.in_apply(x, stats, act, residual, y, halo_mode)
+        from gan_variant_research_amd.runtime import View
+        y32 = View(torch.zeros(y.t.numel()), y.B, y.H, y.W, y.C, y.halo, 0) if y8 is not None else None
+        b32 = self.in_apply(x, stats, act, residual, y32, halo_mode) if y8 is not None else None
 
         def op():
             a()
             b()
+            if y8 is not None:        # the kernel converts its fp32 values, not the rounded bf16 ones
+                b32()
+                y8.padded().copy_(y32.padded().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8))
         return op
 
     def in_stats_from_parts(self, parts, nparts, B, Cc, HW, eps, stats):
@@ -230,7 +236,7 @@ class EmuOps:
             return 0
         if c.Wo < 16 or c.Wo & (c.Wo - 1) or 128 % c.Wo or c.max_tapoff != (2 * c.x.Wp + 2) * c.Cx:
             return 0
-        if (128 // c.Wo + 2) * ((c.Wo + 2 + 7) // 8 * 8) > 320:
+        if (128 // c.Wo + 2) * ((c.Wo + 2 + 7) // 8 * 8) > 320 and c.Wo != 128:      # 128-wide maps: the row-ring variant
             return 0
         bps = (c.N // 128) * (c.Cx // 64)
         spi = (256 + c.B * bps - 1) // (c.B * bps)
