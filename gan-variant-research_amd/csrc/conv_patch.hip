@@ -550,11 +550,11 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
 
 template <int BM, int WGN, int NT, bool FP8 = false, int NS = 7>
 __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) { conv_patch_body<BM, WGN, NT, FP8, NS>(a); }
-// the fp8 variants are capped at 216 registers like the bf16 input-gradient kernel: the other streams' kernels (weight-gradient
-// reduction, InstanceNorm passes) keep 80 registers per SIMD lane to run beside them (uncapped, the compiler takes all 256 and the
-// step loses 0.8 ms to the serialisation)
-__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_num_vgpr(216))) void conv_patch_fp8_kernel(PatchArgs a) { conv_patch_body<256, 2, 0, true, 7>(a); }
-__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_num_vgpr(216))) void conv_patch_fp8_wide_kernel(PatchArgs a) { conv_patch_body<256, 2, 0, true, 9>(a); }
+// The fp8 variants take all 256 registers (two 32-byte weight sets, one activation set, 64 accumulators and the compiler's scheduling
+// slack), so nothing of another stream runs beside them.  Capping them (`amdgpu_num_vgpr(108)`: on gfx90a+ the request is doubled, a
+// request of 216 is silently dropped) was measured: 216 registers = 304 bytes of scratch per lane inside the tap loop, 3x slower.
+__global__ __launch_bounds__(NTHR) void conv_patch_fp8_kernel(PatchArgs a) { conv_patch_body<256, 2, 0, true, 7>(a); }
+__global__ __launch_bounds__(NTHR) void conv_patch_fp8_wide_kernel(PatchArgs a) { conv_patch_body<256, 2, 0, true, 9>(a); }
 
 }  // namespace
 
