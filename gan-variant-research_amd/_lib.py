@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libmi355x_gan.so")
 
 F32, BF16, FP8 = 0, 1, 2     # FP8: OCP e4m3 operand copies of the bottleneck convolutions (BASELINE.json configs[4])
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
-HALO_NONE, HALO_ZERO, HALO_REFLECT = 0, 1, 2
+HALO_NONE, HALO_ZERO, HALO_REFLECT, HALO_REPLICATE = 0, 1, 2, 3
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -91,6 +91,7 @@ PROTOTYPES = {
     "gan_in_bwd": (C.c_int, [PV, vp, C.c_int, PV, C.c_int, PV, PV, vp, vp]),
     "gan_in_bwd_bias": (C.c_int, [PV, vp, C.c_int, PV, C.c_int, PV, PV, vp, vp, C.c_int, C.c_int, vp]),
     "gan_fold_add": (C.c_int, [PV, PV, C.c_int, PV, vp]),
+    "gan_pad_fold": (C.c_int, [PV, C.c_int, PV, vp]),
     "gan_act_bwd": (C.c_int, [PV, C.c_int, PV, C.c_int, PV, PV, vp]),
     "gan_nchw_to_view": (C.c_int, [vp, C.c_int, PV, C.c_int, vp]),
     "gan_view_to_nchw": (C.c_int, [PV, C.c_int, vp, vp]),

@@ -576,10 +576,46 @@ __global__ __launch_bounds__(NTHR, 6) void fold_add_kernel(DView a, int has_a, D
 }
 
 // ------------------------------------------------------------------ layout boundary
+// gradient of a padding layer (gan_pad_fold): every interior pixel adds up the padded positions the padding copied from it
+template <typename T>
+__global__ void pad_fold_kernel(DView g, int mode, DView out) {
+  constexpr int N = Chunk<T>::N;
+  const int nck = out.C / N, py = g.y0, px = g.x0;
+  const int64_t total = (int64_t)out.B * out.H * out.W * nck;
+  const T* gp = reinterpret_cast<const T*>(g.ptr);
+  T* op = reinterpret_cast<T*>(out.ptr);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ck = (int)(i % nck);
+    int64_t r = i / nck;
+    const int x = (int)(r % out.W); r /= out.W;
+    const int y = (int)(r % out.H);
+    const int b = (int)(r / out.H);
+    float acc[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[e] = 0.f;
+    // candidates: the pixel's own padded position and the 2*pad halo rows / columns (at most (2*pad+1)^2 positions, most rejected)
+    for (int jy = 0; jy <= 2 * py; ++jy) {
+      const int yp = jy == 2 * py ? y + py : (jy < py ? jy : g.H + jy);
+      const int sy = mode == GAN_HALO_REFLECT ? reflect_idx(yp - py, g.H) : min(max(yp - py, 0), g.H - 1);
+      if (sy != y) continue;
+      for (int jx = 0; jx <= 2 * px; ++jx) {
+        const int xp = jx == 2 * px ? x + px : (jx < px ? jx : g.W + jx);
+        const int sx = mode == GAN_HALO_REFLECT ? reflect_idx(xp - px, g.W) : min(max(xp - px, 0), g.W - 1);
+        if (sx != x) continue;
+        float t[N];
+        Chunk<T>::load(gp + g.pixp(b, yp, xp) + ck * N, t);
+#pragma unroll
+        for (int e = 0; e < N; ++e) acc[e] += t[e];
+      }
+    }
+    Chunk<T>::store(op + out.pix(b, y, x) + ck * N, acc);
+  }
+}
+
 template <typename T>
 __global__ void nchw_to_view_kernel(const float* __restrict__ src, int C, DView dst, int halo_mode) {
   constexpr int N = Chunk<T>::N;
-  const bool padded = halo_mode == GAN_HALO_REFLECT;
+  const bool padded = halo_mode == GAN_HALO_REFLECT || halo_mode == GAN_HALO_REPLICATE;
   const int DH = padded ? dst.H + 2 * dst.y0 : dst.H, DW = padded ? dst.W + 2 * dst.x0 : dst.W;
   const int nck = dst.C / N;
   const int64_t total = (int64_t)dst.B * DH * DW * nck;
@@ -591,7 +627,8 @@ __global__ void nchw_to_view_kernel(const float* __restrict__ src, int C, DView 
     const int dy = (int)(r % DH);
     const int b = (int)(r / DH);
     int sy = dy, sx = dx;
-    if (padded) { sy = reflect_idx(dy - dst.y0, dst.H); sx = reflect_idx(dx - dst.x0, dst.W); }
+    if (halo_mode == GAN_HALO_REPLICATE) { sy = min(max(dy - dst.y0, 0), dst.H - 1); sx = min(max(dx - dst.x0, 0), dst.W - 1); }
+    else if (padded) { sy = reflect_idx(dy - dst.y0, dst.H); sx = reflect_idx(dx - dst.x0, dst.W); }
     float v[N];
 #pragma unroll
     for (int e = 0; e < N; ++e) {
@@ -926,6 +963,22 @@ extern "C" int gan_fold_add(const gan_view* a, const gan_view* b, int fold, cons
   return 0;
 }
 
+extern "C" int gan_pad_fold(const gan_view* g, int mode, const gan_view* out, void* stream) {
+  VCHK(g, "pad_fold.g"); VCHK(out, "pad_fold.out");
+  if (check_lanes(out, "pad_fold")) return -1;
+  SAME_SHAPE(g, out, "pad_fold(g,out)");
+  GAN_CHECK(mode == GAN_HALO_REPLICATE || mode == GAN_HALO_REFLECT, "pad_fold: mode %d", mode);
+  GAN_CHECK(g->y0 + g->H + g->y0 <= g->Hp && g->x0 + g->W + g->x0 <= g->Wp && (mode == GAN_HALO_REPLICATE || (g->y0 < g->H && g->x0 < g->W)),
+            "pad_fold: g must carry a symmetric halo of y0/x0 pixels");
+  const int epc = out->dtype == GAN_F32 ? 4 : 8;
+  const int64_t total = (int64_t)out->B * out->H * out->W * (out->C / epc);
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  DView vg = to_dview(g), vo = to_dview(out);
+  GAN_DISPATCH_DTYPE(out->dtype, hipLaunchKernelGGL((pad_fold_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, vg, mode, vo);)
+  GAN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int gan_act_bwd(const gan_view* y, int act, const gan_view* g, int fold, const gan_view* g2, const gan_view* dx, void* stream) {
   VCHK(y, "act_bwd.y"); VCHK(g, "act_bwd.g"); VCHK(dx, "act_bwd.dx");
   if (check_lanes(dx, "act_bwd")) return -1;
@@ -945,8 +998,8 @@ extern "C" int gan_act_bwd(const gan_view* y, int act, const gan_view* g, int fo
 extern "C" int gan_nchw_to_view(const float* src, int C, const gan_view* dst, int halo_mode, void* stream) {
   VCHK(dst, "nchw_to_view.dst");
   GAN_CHECK(src && C > 0 && C <= dst->C, "nchw_to_view: bad C=%d", C);
-  const bool padded = halo_mode == GAN_HALO_REFLECT;
-  if (padded) GAN_CHECK(dst->y0 < dst->H && dst->x0 < dst->W && 2 * dst->y0 + dst->H <= dst->Hp && 2 * dst->x0 + dst->W <= dst->Wp, "nchw_to_view: reflect halo does not fit");
+  const bool padded = halo_mode == GAN_HALO_REFLECT || halo_mode == GAN_HALO_REPLICATE;
+  if (padded) GAN_CHECK((halo_mode == GAN_HALO_REPLICATE || (dst->y0 < dst->H && dst->x0 < dst->W)) && 2 * dst->y0 + dst->H <= dst->Hp && 2 * dst->x0 + dst->W <= dst->Wp, "nchw_to_view: halo does not fit");
   const int epc = dst->dtype == GAN_F32 ? 4 : 8;
   const int64_t total = (int64_t)dst->B * (padded ? dst->H + 2 * dst->y0 : dst->H) * (padded ? dst->W + 2 * dst->x0 : dst->W) * (dst->C / epc);
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);

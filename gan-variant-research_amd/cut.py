@@ -66,11 +66,17 @@ class ResNetGenerator(nn.Module):
                  activation="relu", use_attention=True, attn_layers=(3, 7), use_channel_attn=True, channel_attn_layers=(5,),
                  use_style_dropout=True, alpha_min=0.4, alpha_max=0.9):
         super().__init__()
-        if padding_type not in ("reflect", "zero") or activation not in ("relu", "leaky_relu") or norm != "instance" or n_downsampling != 2:
-            raise NotImplementedError("MI355X path: padding_type 'reflect' | 'zero', activation 'relu' | 'leaky_relu', instance norm, 2 downsamplings "
-                                      "(not built: replicate padding, batch / no norm, other depths)")
         self.input_nc, self.output_nc, self.ngf, self.n_blocks = input_nc, output_nc, ngf, n_blocks
-        self.padding_type, self.activation = padding_type, activation
+        self.padding_type, self.activation, self.norm, self.n_downsampling = padding_type, activation, norm, n_downsampling
+        self.compute_dtype = F32
+        # The switches the shipped configs leave at their defaults but the reference's constructor offers (generator_resnet_attn.py:24-66,
+        # 110-162): replicate padding, norm 'batch' | 'none' (any other string is 'none' there too), no block activation, other depths.
+        # The module-granular engine (nets.GeneratorNet) is built for instance norm / reflect | zero / two down-samplings; everything else
+        # is assembled LAYER BY LAYER from the op-level modules (ops_library), with the reference's Sequential indices and state_dict keys.
+        self._layerwise = not (padding_type in ("reflect", "zero") and activation in ("relu", "leaky_relu") and norm == "instance" and n_downsampling == 2)
+        if self._layerwise:
+            self._build_layerwise()
+            return
         rf = padding_type == "reflect"
         if rf:
             s = _slot(4); s[1] = nn.Conv2d(input_nc, ngf, 7)
@@ -91,14 +97,82 @@ class ResNetGenerator(nn.Module):
         self.output = nn.Sequential(*s)
         self.compute_dtype = F32          # BF16: bf16 operands, fp32 accumulation (throughput mode)
 
+    def _build_layerwise(self):
+        """The reference's module tree (generator_resnet_attn.py:104-163, ResidualBlock :19-52) from the op-level modules."""
+        from . import ops_library as L
+        pt, norm, ngf, nd = self.padding_type, self.norm, self.ngf, self.n_downsampling
+        outer_norm = (lambda c: L.InstanceNorm2d(c)) if norm == "instance" else (lambda c: nn.Identity())     # :114,126,150: instance or nothing
+        blk_norm = (lambda c: L.InstanceNorm2d(c)) if norm == "instance" else (lambda c: L.BatchNorm2d(c)) if norm == "batch" else (lambda c: nn.Identity())
+        blk_act = (lambda: nn.ReLU(True)) if self.activation == "relu" else (lambda: nn.LeakyReLU(0.2, True)) if self.activation == "leaky_relu" else (lambda: nn.Identity())
+        m = [L.ReflectionPad2d(3)] if pt == "reflect" else []
+        m += [L.Conv2d(self.input_nc, ngf, 7, padding=0 if pt == "reflect" else 3), outer_norm(ngf), nn.ReLU(True)]
+        self.initial = nn.Sequential(*m)
+        m = []
+        for i in range(nd):
+            m += [L.Conv2d(ngf * 2 ** i, ngf * 2 ** (i + 1), 3, stride=2, padding=1), outer_norm(ngf * 2 ** (i + 1)), nn.ReLU(True)]
+        self.downsample = nn.Sequential(*m)
+        c = ngf * 2 ** nd
+
+        class _Block(nn.Module):
+            def __init__(blk):
+                super().__init__()
+                pad = (lambda: [L.ReflectionPad2d(1)]) if pt == "reflect" else (lambda: [L.ReplicationPad2d(1)]) if pt == "replicate" else (lambda: [])
+                cp = 1 if pt == "zero" else 0          # :36,49 of the reference: only 'zero' pads inside the convolution
+                blk.conv_block = nn.Sequential(*(pad() + [L.Conv2d(c, c, 3, padding=cp), blk_norm(c), blk_act()] + pad() + [L.Conv2d(c, c, 3, padding=cp), blk_norm(c)]))
+
+            def forward(blk, x):
+                return x + blk.conv_block(x)
+        self.res_blocks = nn.ModuleList([_Block() for _ in range(self.n_blocks)])
+        m = []
+        for i in range(nd):
+            cc = ngf * 2 ** (nd - i)
+            m += [L.ConvTranspose2d(cc, cc // 2, 3, stride=2, padding=1, output_padding=1), outer_norm(cc // 2), nn.ReLU(True)]
+        self.upsample = nn.Sequential(*m)
+        m = [L.ReflectionPad2d(3)] if pt == "reflect" else []
+        m += [L.Conv2d(ngf, self.output_nc, 7, padding=0 if pt == "reflect" else 3), nn.Tanh()]
+        self.output = nn.Sequential(*m)
+
+    def _set_layer_dtype(self):
+        from . import ops_library as L
+        L.set_compute_dtype(self.compute_dtype)
+
     def forward(self, x):
         """(B,3,H,W) fp32 in [-1,1] -> (B,3,H,W) fp32 on the HIP kernels, differentiable (autograd.py): one autograd node per call.
         The fused CutTrainer is the fast training path; this is the drop-in nn.Module path."""
+        if self._layerwise:            # generator_resnet_attn.py:165-188, op by op
+            self._set_layer_dtype()
+            x = self.downsample(self.initial(x))
+            for blk in self.res_blocks:
+                x = blk(x)
+            return self.output(self.upsample(x))
         from . import autograd as AG
         return AG.generator_forward(self, x, "cut")
 
     def get_feature_layers(self, x, layer_ids=None):
         """generator_resnet_attn.py:190-235: numbered activations; ids beyond the last one are silently ignored there too."""
+        if self._layerwise:
+            self._set_layer_dtype()
+            ids = list(NCE_LAYERS_DEFAULT) if layer_ids is None else list(layer_ids)
+            feats, idx = [], 0
+            x = self.initial(x)
+            if idx in ids:
+                feats.append(x)
+            idx += 1
+            for seq in (self.downsample, None, self.upsample):
+                if seq is None:
+                    for blk in self.res_blocks:
+                        x = blk(x)
+                        if idx in ids:
+                            feats.append(x)
+                        idx += 1
+                    continue
+                for mod in seq:
+                    x = mod(x)
+                    if isinstance(mod, nn.ReLU):
+                        if idx in ids:
+                            feats.append(x)
+                        idx += 1
+            return feats
         from . import autograd as AG
         ids = feature_layers_present(list(NCE_LAYERS_DEFAULT) if layer_ids is None else list(layer_ids), self.n_blocks)
         return AG.generator_forward(self, x, "cut", ids)
@@ -359,7 +433,7 @@ class CutTrainer:
         self.policy = config["diffaugment"].get("policy", ["color", "translation", "cutout"]) if config["diffaugment"].get("enable", False) else None
         self.aug = DiffAugment(self.policy) if self.policy is not None else None
         self.generator, self.discriminator = generator, discriminator
-        if getattr(generator, "padding_type", "reflect") != "reflect" or getattr(generator, "activation", "relu") != "relu":
+        if getattr(generator, "_layerwise", False) or getattr(generator, "padding_type", "reflect") != "reflect" or getattr(generator, "activation", "relu") != "relu":
             raise NotImplementedError("the fused CutTrainer runs the reference configuration (reflect padding, ReLU blocks); "
                                       "module_step.train_step drives the other generator variants on the same kernels")
         if getattr(discriminator, "num_scales", 1) != 1 or getattr(discriminator, "use_spectral_norm", False):

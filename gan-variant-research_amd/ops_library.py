@@ -26,7 +26,7 @@ import torch
 import torch.nn as nn
 
 from . import autograd as AG
-from ._lib import ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, BF16, F32, HALO_NONE, HALO_REFLECT, HALO_ZERO
+from ._lib import ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, BF16, F32, HALO_NONE, HALO_REFLECT, HALO_REPLICATE, HALO_ZERO
 from .convplan import ConvLayer
 from .runtime import Program, View, cpad
 
@@ -135,6 +135,8 @@ _LIB.define("instance_norm_fwd(Tensor x, float eps, int act, Tensor? residual) -
 _LIB.define("instance_norm_bwd(Tensor x, Tensor stats, Tensor gy, int act) -> Tensor")
 _LIB.define("reflection_pad2d(Tensor x, int pad) -> Tensor")
 _LIB.define("reflection_pad2d_bwd(Tensor gy, int pad) -> Tensor")
+_LIB.define("replication_pad2d(Tensor x, int pad) -> Tensor")
+_LIB.define("replication_pad2d_bwd(Tensor gy, int pad) -> Tensor")
 _LIB.define("act_bwd(Tensor y, Tensor gy, int act) -> Tensor")
 _LIB.define("fused_clip_adam_ema_(Tensor(a!)[] params, Tensor[] grads, Tensor(b!)[] m, Tensor(c!)[] v, Tensor(d!)[] ema, Tensor(e!) steps, float lr, float b1, "
             "float b2, float eps, float max_norm, float grad_scale, float ema_decay) -> Tensor")
@@ -230,40 +232,41 @@ _LIB.impl("instance_norm_bwd", lambda x, stats, gy, act: _in_bwd(_f(x), stats, _
 
 # ---- ReflectionPad2d and the stand-alone activation backward
 class _PadPlan:
-    def __init__(self, device, shape, pad):
+    def __init__(self, device, shape, pad, mode=HALO_REFLECT):
         self.ctx = AG._new_ctx(device, F32)
         ops, ctx = self.ctx.ops, self.ctx
         B, C, H, W = shape
-        assert pad < min(H, W)
+        assert mode == HALO_REPLICATE or pad < min(H, W)
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
         self.x_in, self.y_out = f32(shape), f32(B, C, H + 2 * pad, W + 2 * pad)
         self.g_in, self.dx_out = f32(B, C, H + 2 * pad, W + 2 * pad), f32(shape)
         v = ctx.view(B, H, W, cpad(C), pad)
         whole = View(v.t, B, H + 2 * pad, W + 2 * pad, v.C, 0, v.dtype)       # the padded extent as a plain image (same storage)
         self.fwd = Program("reflection_pad2d")
-        self.fwd.add(ops.nchw_to_view(self.x_in, C, v, HALO_REFLECT))
+        self.fwd.add(ops.nchw_to_view(self.x_in, C, v, mode))
         self.fwd.add(ops.view_to_nchw(whole, C, self.y_out))
         dxv = ctx.view(B, H, W, cpad(C), 0)
-        self.bwd = Program("reflection_pad2d_bwd")
+        self.bwd = Program("pad2d_bwd")
         self.bwd.add(ops.nchw_to_view(self.g_in, C, whole, HALO_NONE))
-        self.bwd.add(ops.fold_add(None, v, True, dxv))
+        # the streaming fold needs H, W >= 2*pad+2 (each pixel receives at most one reflection per axis); small maps take the general one
+        self.bwd.add(ops.fold_add(None, v, True, dxv) if mode == HALO_REFLECT and min(H, W) >= 2 * pad + 2 else ops.pad_fold(v, mode, dxv))
         self.bwd.add(ops.view_to_nchw(dxv, C, self.dx_out))
 
 
-def _pad_plan(shape, device, pad) -> _PadPlan:
-    return _plan(("pad", (device.type, device.index), tuple(shape), pad), lambda: _PadPlan(device, tuple(shape), pad))
+def _pad_plan(shape, device, pad, mode=HALO_REFLECT) -> _PadPlan:
+    return _plan(("pad", (device.type, device.index), tuple(shape), pad, mode), lambda: _PadPlan(device, tuple(shape), pad, mode))
 
 
-def _pad_fwd(x, pad):
-    p = _pad_plan(x.shape, x.device, pad)
+def _pad_fwd(x, pad, mode=HALO_REFLECT):
+    p = _pad_plan(x.shape, x.device, pad, mode)
     p.x_in.copy_(x)
     p.fwd.run()
     return p.y_out.clone()
 
 
-def _pad_bwd(gy, pad):
+def _pad_bwd(gy, pad, mode=HALO_REFLECT):
     B, C, Hp, Wp = gy.shape
-    p = _pad_plan((B, C, Hp - 2 * pad, Wp - 2 * pad), gy.device, pad)
+    p = _pad_plan((B, C, Hp - 2 * pad, Wp - 2 * pad), gy.device, pad, mode)
     p.g_in.copy_(gy)
     p.bwd.run()
     return p.dx_out.clone()
@@ -294,6 +297,8 @@ def _act_bwd(y, gy, act):
 
 _LIB.impl("reflection_pad2d", lambda x, pad: _pad_fwd(_f(x), pad), _IMPL)
 _LIB.impl("reflection_pad2d_bwd", lambda gy, pad: _pad_bwd(_f(gy), pad), _IMPL)
+_LIB.impl("replication_pad2d", lambda x, pad: _pad_fwd(_f(x), pad, HALO_REPLICATE), _IMPL)
+_LIB.impl("replication_pad2d_bwd", lambda gy, pad: _pad_bwd(_f(gy), pad, HALO_REPLICATE), _IMPL)
 _LIB.impl("act_bwd", lambda y, gy, act: _act_bwd(_f(y), _f(gy), act), _IMPL)
 
 
@@ -361,6 +366,10 @@ torch.library.register_autograd("mi355x_gan::reflection_pad2d", lambda ctx, g: (
                                 setup_context=lambda ctx, inputs, output: setattr(ctx, "pad", inputs[1]))
 
 
+torch.library.register_autograd("mi355x_gan::replication_pad2d", lambda ctx, g: (torch.ops.mi355x_gan.replication_pad2d_bwd(g.contiguous(), ctx.pad), None),
+                                setup_context=lambda ctx, inputs, output: setattr(ctx, "pad", inputs[1]))
+
+
 # ------------------------------------------------------------------------------------------------ drop-in modules
 _ACTS = {None: ACT_NONE, "relu": ACT_RELU, "leaky_relu": ACT_LRELU, "tanh": ACT_TANH}
 
@@ -400,3 +409,62 @@ class ReflectionPad2d(nn.Module):
 
     def forward(self, x):
         return torch.ops.mi355x_gan.reflection_pad2d(x, self.padding)
+
+
+class ReplicationPad2d(nn.Module):
+    """nn.ReplicationPad2d (generator_resnet_attn.py:26-27,45-46: padding_type='replicate', off in the shipped configs)."""
+
+    def __init__(self, padding: int):
+        super().__init__()
+        self.padding = int(padding)
+
+    def forward(self, x):
+        return torch.ops.mi355x_gan.replication_pad2d(x, self.padding)
+
+
+class _BatchNormFn(torch.autograd.Function):
+    """Training-mode nn.BatchNorm2d on the InstanceNorm kernels: a (B,C,H,W) batch is ONE (1,C,B*H,W) instance.  The affine part and the
+    running statistics are elementwise / per-channel torch ops (generator_resnet_attn.py:57-58: norm='batch', off in the shipped configs)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        B, C, H, W = x.shape
+        x1 = x.permute(1, 0, 2, 3).reshape(1, C, B * H, W).contiguous()
+        assert abs(eps - IN_EPS) < 1e-12
+        xh1, stats = torch.ops.mi355x_gan.instance_norm_fwd(x1, eps, ACT_NONE, None)
+        xh = xh1.reshape(C, B, H, W).permute(1, 0, 2, 3).contiguous()
+        ctx.save_for_backward(x1, stats, xh, weight)
+        ctx.shape = (B, C, H, W)
+        ctx.mark_non_differentiable(stats)
+        y = xh * weight.view(1, C, 1, 1) + bias.view(1, C, 1, 1)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, gy, _gstats):
+        x1, stats, xh, weight = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        gw, gb = (gy * xh).sum((0, 2, 3)), gy.sum((0, 2, 3))
+        g1 = (gy * weight.view(1, C, 1, 1)).permute(1, 0, 2, 3).reshape(1, C, B * H, W).contiguous()
+        dx1 = torch.ops.mi355x_gan.instance_norm_bwd(x1, stats, g1, ACT_NONE)
+        return dx1.reshape(C, B, H, W).permute(1, 0, 2, 3).contiguous(), gw, gb, None
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """torch.nn.BatchNorm2d (affine, running statistics) whose training-mode normalisation runs on the InstanceNorm kernels."""
+
+    def forward(self, x):
+        assert self.affine and self.track_running_stats
+        if not self.training:
+            scale = self.weight / torch.sqrt(self.running_var + self.eps)
+            return x * scale.view(1, -1, 1, 1) + (self.bias - self.running_mean * scale).view(1, -1, 1, 1)
+        y, stats = _BatchNormFn.apply(x, self.weight, self.bias, float(self.eps))
+        with torch.no_grad():          # running statistics: momentum update with the UNBIASED batch variance (torch semantics)
+            C = x.shape[1]
+            n = x.numel() // C
+            st = stats[:C * 2].view(C, 2)
+            mean, var = st[:, 0], (1.0 / st[:, 1] ** 2 - self.eps)
+            m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked + 1)
+            self.running_mean.mul_(1 - m).add_(mean, alpha=m)
+            self.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
+            self.num_batches_tracked += 1
+        return y

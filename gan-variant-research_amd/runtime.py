@@ -471,6 +471,10 @@ class HipOps:
     def fold_add(self, a: Optional[View], b: View, fold, out: View) -> Op:
         return self._call("gan_fold_add", self._v(a), self._v(b), int(fold), self._v(out), self._s())
 
+    def pad_fold(self, g: View, mode, out: View) -> Op:
+        """Gradient of a padding layer: out = sum of g (which carries the halo) over the padded positions copied from each pixel."""
+        return self._call("gan_pad_fold", self._v(g), mode, self._v(out), self._s())
+
     def act_bwd(self, y: View, act, g: View, fold, g2: Optional[View], dx: View) -> Op:
         return self._call("gan_act_bwd", self._v(y), act, self._v(g), int(fold), self._v(g2), self._v(dx), self._s())
 

@@ -24,7 +24,9 @@ extern "C" {
  * statistic and master weight stays bf16 / fp32.  An fp8 view has C % 16 == 0. */
 enum { GAN_F32 = 0, GAN_BF16 = 1, GAN_FP8 = 2 };
 enum { GAN_ACT_NONE = 0, GAN_ACT_RELU = 1, GAN_ACT_LRELU = 2, GAN_ACT_TANH = 3 };
-enum { GAN_HALO_NONE = 0, GAN_HALO_ZERO = 1, GAN_HALO_REFLECT = 2 };
+/* GAN_HALO_REPLICATE (nn.ReplicationPad2d, generator_resnet_attn.py:26-27,45-46: an option the shipped configs do not use): accepted by
+ * gan_nchw_to_view only; its gradient is gan_pad_fold */
+enum { GAN_HALO_NONE = 0, GAN_HALO_ZERO = 1, GAN_HALO_REFLECT = 2, GAN_HALO_REPLICATE = 3 };
 
 /* A halo-NHWC activation: `ptr` addresses element [0][0][0][0] of the allocation; the logical HxW image
  * starts at (y0,x0).  dtype: GAN_F32 or GAN_BF16. */
@@ -202,6 +204,9 @@ int gan_bias_finalize_batch(const gan_bias_part_desc* descs, int n, int total_bl
 int gan_in_bwd_amax(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* dx, float* ws,
                     float* bias_part, float* amax, void* stream);
 int gan_fold_add(const gan_view* a, const gan_view* b, int fold, const gan_view* out, void* stream);
+/* gradient of a padding layer: out[b][y][x] = sum of g over the padded positions (g carries a halo of y0/x0 pixels) that the padding
+ * copies from (y,x); mode GAN_HALO_REPLICATE (nn.ReplicationPad2d: an edge pixel collects its whole halo run) or GAN_HALO_REFLECT */
+int gan_pad_fold(const gan_view* g, int mode, const gan_view* out, void* stream);
 /* dx = g * act'(y) (tanh: 1-y^2, lrelu: y>0?1:0.2), g optionally folded; written to the interior of dx */
 int gan_act_bwd(const gan_view* y, int act, const gan_view* g, int fold, const gan_view* g2, const gan_view* dx, void* stream);
 

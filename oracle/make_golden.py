@@ -8,6 +8,7 @@ registered in sys.modules for that import.
 """
 from __future__ import annotations
 
+import copy
 import os
 import sys
 import types
@@ -338,6 +339,75 @@ def gen_optional(tc):
     np.savez_compressed(os.path.join(OUT, "cut_optional.npz"), **_np(out))
 
 
+VARIANTS = {  # tag: ResNetGenerator keyword arguments (ngf=8 unless stated, n_blocks=2: small vectors)
+    "grep": dict(padding_type="replicate", activation="relu"),
+    "gbn": dict(padding_type="reflect", activation="relu", norm="batch"),
+    "gnn": dict(padding_type="zero", activation="identity", norm="none"),
+    "gd1": dict(padding_type="reflect", activation="relu", n_downsampling=1),
+    "gd3": dict(padding_type="replicate", activation="leaky_relu", n_downsampling=3, ngf=4),
+}
+
+
+def gen_variants(tc):
+    """The remaining constructor switches of the reference's ResNetGenerator (generator_resnet_attn.py:24-66, 100-163):
+    replicate padding, norm 'batch' / 'none' in the residual blocks (the outer layers then carry no norm at all), a block without
+    activation, one and three down-samplings.  Same quantities as the gz / grl vectors of cut_optional.npz; for 'batch' also the
+    running statistics after the two training-mode forwards and the eval-mode output."""
+    from GAN_Variant1.models.generator_resnet_attn import ResNetGenerator
+    from GAN_Variant1.utils.seed_dist import set_seed
+
+    def margin(Gm, x):
+        """Smallest |input| any ReLU / LeakyReLU sees, relative to that tensor's largest: a pre-activation within rounding distance of
+        zero makes the gradient vectors a coin flip between two correct implementations (the kink), so each variant's input seed is
+        advanced until it is well conditioned."""
+        worst = [1.0]
+        hooks = [m.register_forward_pre_hook(lambda _m, inp: worst.__setitem__(0, min(worst[0], float(inp[0].abs().min() / inp[0].abs().max()))))
+                 for m in Gm.modules() if isinstance(m, (torch.nn.ReLU, torch.nn.LeakyReLU))]
+        with torch.no_grad():
+            Gm(x)
+        for h in hooks:
+            h.remove()
+        return worst[0]
+
+    out = {}
+    for t, (tag, kw) in enumerate(VARIANTS.items()):
+        set_seed(11)
+        Gv = ResNetGenerator(3, 3, **{"ngf": 8, "n_blocks": 2, **kw})
+        for seed in range(1000 * (t + 1), 1000 * (t + 1) + 500):
+            g = torch.Generator().manual_seed(seed)
+            x = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+            if margin(copy.deepcopy(Gv), x) > 8e-6:      # a copy: the probe must not move BatchNorm's running statistics
+                break
+        else:
+            raise RuntimeError("no well-conditioned input found")
+        out[f"{tag}.x"], out[f"{tag}.seed"] = x, np.asarray(seed)
+        for k, v in Gv.state_dict().items():
+            out[f"{tag}.init.{k}"] = torch.cat([v.reshape(-1)[:4].double(), v.double().sum().reshape(1)])
+        nlayers = 1 + kw.get("n_downsampling", 2) * 2 + 2
+        ids = [0, 2, nlayers - 2]
+        xr = x.clone().requires_grad_(True)
+        yv = Gv(xr)
+        feats = Gv.get_feature_layers(xr, ids)
+        wv = torch.randn(yv.shape, generator=g)
+        loss = (yv * wv).sum() + sum((f * f).mean() for f in feats)
+        names = [k for k, _ in Gv.named_parameters()]
+        grads = torch.autograd.grad(loss, [xr] + [p_ for _, p_ in Gv.named_parameters()])
+        out[f"{tag}.ids"] = np.asarray(ids)
+        out[f"{tag}.w"], out[f"{tag}.y"], out[f"{tag}.loss"], out[f"{tag}.gx"] = wv, yv.detach(), loss.detach(), grads[0]
+        for i, f in enumerate(feats):
+            out[f"{tag}.feat{i}"] = f.detach().clone()
+        for k, gr in zip(names, grads[1:]):
+            out[f"{tag}.gw.{k}"] = gr
+        if kw.get("norm") == "batch":
+            for k, v in Gv.state_dict().items():
+                if "running" in k or "num_batches" in k:
+                    out[f"{tag}.after.{k}"] = v.clone()
+            Gv.eval()
+            with torch.no_grad():
+                out[f"{tag}.eval_y"] = Gv(x).clone()
+    np.savez_compressed(os.path.join(OUT, "cut_variants.npz"), **_np(out))
+
+
 def gen_input():
     """Input-pipeline fixture: small images through the reference's transform chains, executed by Pillow (the library behind the
     reference's torchvision transforms; torchvision itself is absent here) -- oracle/input_ref.py:apply_pil."""
@@ -366,11 +436,16 @@ def main():
         return
     tc = _import_reference()
     gen_input()
+    if len(sys.argv) > 1 and sys.argv[1] == "variants":
+        gen_variants(tc)
+        print("cut_variants.npz", os.path.getsize(os.path.join(OUT, "cut_variants.npz")))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "optional":
         gen_optional(tc)
         print("cut_optional.npz", os.path.getsize(os.path.join(OUT, "cut_optional.npz")))
         return
     gen_optional(tc)
+    gen_variants(tc)
     gen_models(tc)
     gen_losses(tc)
     gen_optim(tc)

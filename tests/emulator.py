@@ -417,6 +417,18 @@ class EmuOps:
             dst.padded().copy_(v.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8))
         return op
 
+    def pad_fold(self, g, mode, out):
+        def op():
+            full = g.padded().float()
+            p, H, W = g.halo, g.H, g.W
+            idx = (lambda n: _reflect(torch.arange(-p, n + p), n)) if mode == HALO_REFLECT else (lambda n: torch.arange(-p, n + p).clamp(0, n - 1))
+            tmp = torch.zeros(g.B, H, g.Wp, g.C)
+            tmp.index_add_(1, idx(H), full)
+            res = torch.zeros(g.B, H, W, g.C)
+            res.index_add_(2, idx(W), tmp)
+            _store(out, res)
+        return op
+
     def fold_add(self, a, b, fold, out):
         def op():
             v = _fold(b, fold)
@@ -441,6 +453,10 @@ class EmuOps:
                 p = dst.halo
                 ys = _reflect(torch.arange(-p, dst.H + p), dst.H)
                 xs = _reflect(torch.arange(-p, dst.W + p), dst.W)
+                _store(dst, v[:, ys][:, :, xs], padded_coords=True)
+            elif halo_mode == 3:       # replicate
+                p = dst.halo
+                ys, xs = torch.arange(-p, dst.H + p).clamp(0, dst.H - 1), torch.arange(-p, dst.W + p).clamp(0, dst.W - 1)
                 _store(dst, v[:, ys][:, :, xs], padded_coords=True)
             else:
                 _store(dst, v)

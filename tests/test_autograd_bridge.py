@@ -233,6 +233,64 @@ def generator_variant_cases(device, tol, tags=("gz", "grl")):
                 _close(gr, T(f"{tag}.gw.{k}"), tol * 5, f"{tag} grad {k}")
 
 
+def generator_switch_cases(device, tol, tags):
+    """The remaining constructor switches (replicate padding, norm 'batch' / 'none', no block activation, 1 and 3 down-samplings):
+    cut.ResNetGenerator assembles these layer by layer from the op-level modules (ops_library) with the reference's Sequential indices.
+    Against vectors the reference produced (cut_variants.npz, oracle/make_golden.py:gen_variants)."""
+    import os
+    from oracle.make_golden import VARIANTS
+    from gan_variant_research_amd import ops_library as L
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cut_variants.npz"))
+    T = lambda k: torch.from_numpy(np.asarray(g[k])).to(device)
+    for tag in tags:
+        kw = VARIANTS[tag]
+        L._PLANS.clear()
+        C.set_seed(11)
+        G = C.ResNetGenerator(3, 3, **{"ngf": 8, "n_blocks": 2, **kw})
+        assert G._layerwise
+        keys = [k[len(tag) + 6:] for k in g.files if k.startswith(f"{tag}.init.")]
+        assert list(G.state_dict()) == keys, (list(G.state_dict())[:6], keys[:6])
+        for k, v in G.state_dict().items():
+            want = g[f"{tag}.init.{k}"]
+            np.testing.assert_allclose(np.concatenate([v.reshape(-1)[:4].double().numpy(), [float(v.double().sum())]]), want, rtol=1e-6, atol=1e-7, err_msg=k)
+        G = G.to(device)
+        x = T(f"{tag}.x")
+        xr = x.clone().requires_grad_(True)
+        y = G(xr)
+        feats = G.get_feature_layers(xr, [int(i) for i in g[f"{tag}.ids"]])
+        _close(y, T(f"{tag}.y"), tol, f"{tag} G(x)")
+        for i, f in enumerate(feats):
+            _close(f, T(f"{tag}.feat{i}"), tol, f"{tag} feature {i}")
+        loss = (y * T(f"{tag}.w")).sum() + sum((f * f).mean() for f in feats)
+        _close(loss, T(f"{tag}.loss"), tol, f"{tag} loss")
+        names = [k for k, _ in G.named_parameters()]
+        grads = torch.autograd.grad(loss, [xr] + [p for _, p in G.named_parameters()])
+        _close(grads[0], T(f"{tag}.gx"), tol * 5, f"{tag} dL/dx")
+        mods = dict(G.named_modules())
+
+        def rounding_noise(k):      # a conv bias in front of a mean-removing norm: gradient identically zero, both sides hold rounding noise
+            if not k.endswith(".bias") or k.startswith("output") or not isinstance(mods[k.rsplit(".", 1)[0]], (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                return False
+            norm = kw.get("norm", "instance")
+            return norm == "instance" or (norm == "batch" and "conv_block" in k)
+        for k, gr in zip(names, grads[1:]):
+            if not rounding_noise(k):
+                _close(gr, T(f"{tag}.gw.{k}"), tol * 5, f"{tag} grad {k}")
+        if kw.get("norm") == "batch":
+            for k, v in G.state_dict().items():
+                if "running" in k or "num_batches" in k:
+                    _close(v.double(), T(f"{tag}.after.{k}").double(), tol, f"{tag} {k} after two training-mode forwards")
+            G.eval()
+            with torch.no_grad():
+                _close(G(x), T(f"{tag}.eval_y"), tol, f"{tag} eval-mode output")
+
+
+@pytest.mark.parametrize("tag", ["grep", "gbn", "gnn", "gd1", "gd3"])
+def test_generator_switches_on_emulator(monkeypatch, tag):
+    monkeypatch.setattr(AG, "_OPS_FACTORY", lambda device: EmuOps())
+    generator_switch_cases(torch.device("cpu"), 2e-4, tags=(tag,))
+
+
 @pytest.mark.parametrize("tag", ["gz", "grl"])
 def test_generator_variants_on_emulator(monkeypatch, tag):
     monkeypatch.setattr(AG, "_OPS_FACTORY", lambda device: EmuOps())

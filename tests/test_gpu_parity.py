@@ -351,6 +351,21 @@ def test_generator_variants_hip(tag):
     generator_variant_cases(torch.device(DEV), 5e-4, tags=(tag,))
 
 
+@pytest.mark.parametrize("tag", ["grep", "gbn", "gnn", "gd1", "gd3"])
+def test_generator_switches_hip(tag):
+    """The remaining constructor switches (replicate padding, norm 'batch' / 'none', no block activation, 1 / 3 down-samplings): the
+    layer-wise generator on the HIP kernels vs vectors produced by the reference (tests/golden/cut_variants.npz)."""
+    from tests.test_autograd_bridge import generator_switch_cases
+    generator_switch_cases(torch.device(DEV), 5e-4, tags=(tag,))
+
+
+def test_pad_ops_hip():
+    """mi355x_gan::replication_pad2d / reflection_pad2d and their gradients (gan_nchw_to_view halo modes, gan_pad_fold, gan_fold_add)
+    against torch.nn.functional.pad, ragged sizes and pads 1..3."""
+    from tests.test_ops_library import pad_op_cases
+    pad_op_cases(DEV)
+
+
 @pytest.mark.parametrize("H", [32, 37])
 def test_first_conv_window_kernel_fused_statistics(H):
     """The 3 -> 64 channel 7x7 window kernel also writes per-tile (sum, sum of squares): with gan_in_stats_from_parts they are the

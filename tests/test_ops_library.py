@@ -129,10 +129,35 @@ def fused_adam_case(device):
     assert steps.tolist() == [3, 3, 3]
 
 
+def pad_op_cases(device):
+    """replication_pad2d / reflection_pad2d and their gradients against torch.nn.functional.pad: ragged sizes, pads 1..3, maps too
+    small for the streaming fold (H < 2*pad+2: the general gan_pad_fold takes over)."""
+    import torch.nn.functional as F
+    from gan_variant_research_amd import ops_library as L  # noqa: F401
+    torch.manual_seed(5)
+    for (B, Cc, H, W), pad in (((2, 8, 9, 7), 1), ((1, 24, 6, 5), 3), ((2, 3, 16, 16), 2), ((1, 8, 4, 4), 1)):
+        for name, mode in (("replication_pad2d", "replicate"), ("reflection_pad2d", "reflect")):
+            x = torch.randn(B, Cc, H, W, device=device, requires_grad=True)
+            y = getattr(torch.ops.mi355x_gan, name)(x, pad)
+            xr = x.detach().cpu().requires_grad_(True)
+            yr = F.pad(xr, (pad,) * 4, mode=mode)
+            assert torch.equal(y.detach().cpu(), yr.detach()), (name, pad)
+            w = torch.randn(yr.shape)
+            g, = torch.autograd.grad((y * w.to(device)).sum(), x)
+            gr, = torch.autograd.grad((yr * w).sum(), xr)
+            np.testing.assert_allclose(g.cpu().numpy(), gr.numpy(), rtol=1e-6, atol=1e-6, err_msg=f"{name} pad {pad}")
+
+
+def test_pad_ops_on_emulator(monkeypatch):
+    monkeypatch.setattr(AG, "_OPS_FACTORY", lambda device: EmuOps())
+    pad_op_cases("cpu")
+
+
 def test_ops_are_registered_with_schemas():
     from gan_variant_research_amd import ops_library as L  # noqa: F401
     for name in ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad", "conv_transpose2d_fwd", "conv_transpose2d_dgrad", "conv_transpose2d_wgrad",
-                 "instance_norm_fwd", "instance_norm_bwd", "reflection_pad2d", "reflection_pad2d_bwd", "fused_clip_adam_ema_"):
+                 "instance_norm_fwd", "instance_norm_bwd", "reflection_pad2d", "reflection_pad2d_bwd", "replication_pad2d", "replication_pad2d_bwd",
+                 "fused_clip_adam_ema_"):
         op = getattr(torch.ops.mi355x_gan, name)
         assert "Tensor" in str(op.default._schema), name
 
