@@ -29,7 +29,7 @@ class GanConvDesc(C.Structure):
                 ("tapoff", vp), ("w", vp), ("bias", vp), ("out", vp),
                 ("out_Hp", i32), ("out_Wp", i32), ("out_C", i32), ("out_y0", i32), ("out_x0", i32), ("out_sy", i32), ("out_sx", i32),
                 ("act", i32), ("mask", vp), ("mask_Hp", i32), ("mask_Wp", i32), ("mask_y0", i32), ("mask_x0", i32), ("stats", vp), ("max_tapoff", i32), ("w_layout", i32),
-                ("win_ty0", i32), ("win_tx0", i32), ("tile_rows", i32), ("_pad", i32), ("w_scale", vp), ("in_scale", vp)]
+                ("win_ty0", i32), ("win_tx0", i32), ("tile_rows", i32), ("tile_cols", i32), ("w_scale", vp), ("in_scale", vp)]
 
 
 class GanWgradDesc(C.Structure):
@@ -73,6 +73,7 @@ PROTOTYPES = {
     "gan_wgrad_reduce": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "gan_conv_patch_ok": (C.c_int, [PC]),
     "gan_conv_patch_tile_rows": (C.c_int, [PC]),
+    "gan_conv_patch_tile_cols": (C.c_int, [PC]),
     "gan_conv_stats_parts": (C.c_int, [PC]),
     "gan_in_stats_from_parts": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp]),
     "gan_pack_weight": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),

@@ -71,6 +71,7 @@ class _Pack:
         if not self.ctx.ops.conv_patch_ok(c):
             raise GanError(f"fp8 convolution: B{c.B} {c.Ho}x{c.Wo} Cin{c.Cin} taps{c.ntaps} does not qualify for the range-patch kernel")
         c.tile_rows = self.ctx.ops.conv_patch_tile_rows(c)
+        c.tile_cols = self.ctx.ops.conv_patch_tile_cols(c)
         return c
 
     def pack_ops(self, master: torch.Tensor):
@@ -91,6 +92,7 @@ class _Pack:
         if self.ctx.ops.conv_patch_ok(c):
             c.w, c.w_frag = self.wf, True
             c.tile_rows = self.ctx.ops.conv_patch_tile_rows(c)
+            c.tile_cols = self.ctx.ops.conv_patch_tile_cols(c)
         else:
             c.w, c.w_frag = self.w, False
             # the 64 -> 3 channel 7x7 layers: the window kernel reads the same row-major weight copy
@@ -234,6 +236,7 @@ class ConvLayer:
                 n = ops.conv_stats_parts(call)
                 if 0 < n and x.B * n * y.C * 2 <= stats_ws.numel():
                     call.stats, self.stats_parts = stats_ws, n
+            self.last_call = call          # the planned forward call (tests read the tile the planner chose)
             return [ops.conv_igemm(call)]
         assert (y.H, y.W) == (2 * x.H, 2 * x.W)
         return self._phased(self.fwd_packs, x, y, act, self.bias_k if use_bias else None, mask)

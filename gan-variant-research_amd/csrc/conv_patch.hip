@@ -44,7 +44,8 @@ struct PatchArgs {
   unsigned long long* stamps;   // diagnostic build only (GAN_PATCH_STAMPS): [block][32] s_memtime stamps of wave 0
 };
 
-constexpr int BN = 128, NTHR = 512;   // the tile height BM is a template parameter: 256 (4 x 2 waves of 64 x 64) or 288 (2 x 4 waves of 144 x 32)
+constexpr int NTHR = 512;   // the tile is a template parameter: BM = 256 (4 x 2 waves of 64 x 64) or 288 (2 x 4 waves of 144 x 32) rows by BN = 128 channels,
+                            // or BM x 256 with 2 x 4 waves of (BM/2) x 64 (the whole Cout of the residual layers in one tile; see the BN == 256 loop)
 // 8 waves = (8/WGN) pixel groups x WGN channel groups.  Measured on the 3x3 256->256 layer (s_memtime stamps, cycles per
 // 64-channel slab): 4 x 2 (64 x 64 per wave) 15.5 k, 2 x 4 (128 x 32 per wave, half the weight bytes through the vector L1,
 // twice the LDS reads) 16.0 k; MFMA alone would be 9.2 k.  Neither operand path is the limiter: with two waves per SIMD each
@@ -76,7 +77,7 @@ __device__ __forceinline__ int pixbase(const PatchArgs& a, int b, int m) {
   const int ho = m / a.Wo, wo = m - ho * a.Wo;
   return (b * a.in_Hp + ho * a.in_sy + a.in_y0) * a.in_Wp + wo * a.in_sx + a.in_x0;
 }
-template <int BM>
+template <int BM, int BN>
 __device__ __forceinline__ TileGeo tile_geo(const PatchArgs& a, int tau) {
   TileGeo g;
   const int mt = tau / a.NTILES;
@@ -97,9 +98,10 @@ __device__ __forceinline__ TileGeo tile_geo(const PatchArgs& a, int tau) {
 // moved the fp8 MFMA takes the cycles of the two bf16 MFMAs it replaces: twice the FLOPs per byte, HBM and LDS traffic halved.
 typedef __attribute__((ext_vector_type(8))) int v8i_t;
 typedef __attribute__((ext_vector_type(4))) int v4i_t;
-template <int BM, int WGN, int NT, bool FP8 = false, int NS = 7>
+template <int BM, int WGN, int NT, bool FP8 = false, int NS = 7, int BN = 128>
 __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
   static_assert(!FP8 || NT == 0, "the fp8 path uses the generic tap loop");
+  static_assert(BN == 128 || (BN == 256 && WGN == 4 && NT == 0 && !FP8), "256-channel tiles: 2 x 4 waves, generic tap loop, bf16");
   constexpr int NSLICE = NS, PATCHB = NS * 64 * 128;
   constexpr int FI = BM / (8 / WGN) / 16, FJ = BN / WGN / 16;   // fragments per wave: FI pixel groups x FJ channel groups
   extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -107,7 +109,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
   int32_t* taptab = reinterpret_cast<int32_t*>(lds + 2 * PATCHB);
   float* stsh = reinterpret_cast<float*>(lds + 2 * PATCHB + 512);   // [8 waves][16*FJ channels][2]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave roles are scalars: nothing derived from them costs a VGPR
   for (int i = tid; i < a.ntaps; i += NTHR) taptab[i] = a.tapoff[i] / a.tapdiv;   // pixel offsets
   int stoff[NT > 0 ? NT : 1];   // static schedule: pixel offset of every tap, wave-uniform
   if constexpr (NT > 0) {
@@ -163,7 +165,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
     }
   };
   stamp();
-  TileGeo g = tile_geo<BM>(a, tau);
+  TileGeo g = tile_geo<BM, BN>(a, tau);
   // prologue: first slab -> LDS buffer 0, first tap's weights -> registers
   {
     u32x4_t tmp[NSLICE];
@@ -202,7 +204,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
     const int tau_next = tau + G;
     const bool has_next = tau_next < a.tiles;
     TileGeo gn = g;
-    if (has_next) gn = tile_geo<BM>(a, tau_next);
+    if (has_next) gn = tile_geo<BM, BN>(a, tau_next);
 
     f32x4_t acc[FI][FJ];
 #pragma unroll
@@ -369,6 +371,85 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
         pcur ^= 1;
         stamp();
       }
+    } else if constexpr (BN == 256) {
+      // 256-channel tile: a wave owns (BM/2) x 64 outputs = 8-9 pixel fragments x 4 channel fragments, 32-36 MFMAs per k-step against
+      // 12-13 operand fetches (the 128-channel tiles: 16 against 8), and the slab is staged once for the whole Cout.  An MFMA holds the
+      // SIMD's vector issue for 8 of its 16 cycles, so what limits the 128-channel tiles is the ~30 other instructions per 16 MFMAs of
+      // two waves sharing one issue port; here there are ~20 per 36.  Registers: 128-144 accumulators, ONE weight set and ONE set of
+      // activation fragments: a k-step runs channel-fragment-major, a fragment's weights are refetched for the next k-step as soon as
+      // its FI MFMAs are issued (27 MFMAs of cover for the L2 latency) and the activation fragments are re-read during the last
+      // channel fragment, each right after the MFMA that consumes it (8 MFMAs of cover for the LDS latency).
+      // The k-steps are branch-free (hipcc's s_waitcnt insertion turns conservative -- vmcnt(0) right behind the weight fetches -- at
+      // every join): the 7 slices of the next slab ride on the first 8 k-steps, which are unrolled with their slice numbers as
+      // constants (the descriptor has >= 4 taps); after the block's last slab the staging re-reads the current tile into the idle buffer.
+      // Measured on the 3x3 256->256 layer, B = 16 (s_memtime, cycles per 64-channel slab; MFMA alone 18.4 k / 20.7 k): 256 rows 24.1 k,
+      // 288 rows 27.3 k = 76 % (the 128-channel tiles: 69-73 %) and half the epilogues; forward 65.6 -> 60.6 us, input gradient 75.7 -> 68.0 us.
+      static_assert(NSLICE == 7, "the staging schedule of the 256-channel tiles is written for 7 slices");
+      for (int c = 0; c < a.nchunk; ++c) {
+        const bool last_chunk = c + 1 == a.nchunk;
+        const TileGeo gs = last_chunk ? gn : g;
+        const int cs = last_chunk ? 0 : c + 1;
+        const char* pb = pbuf + pcur * PATCHB;
+        u32x4_t stg = {0, 0, 0, 0};
+        uint32_t xaddr[FI];
+        auto x_addr = [&](int toff) {
+#pragma unroll
+          for (int i = 0; i < FI; ++i) {
+            const int prow = lbase[i] + toff;
+            xaddr[i] = (uint32_t)(prow * 128 + ((fg ^ (prow & 7)) << 4));
+          }
+        };
+        // one k-step: multiplies (w, Xa), refetches w for the k-step (n0_next, kb_next), re-reads Xa[i] at xaddr[i] ^ flip, and moves
+        // one slice of the next slab: SS = slice written to LDS (fetched by the previous k-step), LS = slice fetched; -1: none
+        auto kstep = [&](auto ss_tag, auto ls_tag, u32x4_t (&w)[FJ], int n0_next, int kb_next, uint32_t flip) {
+          constexpr int SS = decltype(ss_tag)::value, LS = decltype(ls_tag)::value;
+          const int base = __builtin_amdgcn_readfirstlane((((n0_next + wn_u * (16 * FJ)) >> 4) * a.KB + kb_next) * 1024);
+#pragma unroll
+          for (int j = 0; j < FJ; ++j) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[j]), __builtin_bit_cast(bf16x8_t, Xa[i]), acc[i][j], 0, 0, 0);
+              if (j == FJ - 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                Xa[i] = *reinterpret_cast<const u32x4_t*>(pb + (xaddr[i] ^ flip));
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            w[j] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, base + j * a.KB * 1024, 0));
+            if (j == 0) {
+              if constexpr (SS >= 0) slab_store(pcur ^ 1, SS, stg);
+              if constexpr (LS >= 0) stg = slab_load(gs, cs, LS);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        using std::integral_constant;
+        auto tap = [&](auto s0, auto l0, auto s1, auto l1, int t) {
+          const bool last_tap = t + 1 == a.ntaps;
+          const int toff_next = taptab[last_tap ? t : t + 1];     // read a k-step before its use (after the last tap: a harmless re-read)
+          const int nt = last_tap ? 0 : t + 1;
+          const int nc = last_tap ? (last_chunk ? 0 : c + 1) : c;
+          const int nn0 = (last_tap && last_chunk) ? gn.n0 : g.n0;
+          const int kb_cur = kb_of(c, t), kb_next = kb_of(nc, nt);
+          kstep(s0, l0, Wa, g.n0, kb_cur + 1, 64u);              // first 32 channels of the tap; re-read: the other half of the row
+          x_addr(toff_next);
+          kstep(s1, l1, Wa, nn0, kb_next, 0u);                   // second half; re-read: the next tap
+        };
+        x_addr(taptab[0]);
+#pragma unroll
+        for (int i = 0; i < FI; ++i) Xa[i] = *reinterpret_cast<const u32x4_t*>(pb + xaddr[i]);   // Wa: fetched by the previous slab's last k-step (or the prologue)
+        using IC = integral_constant<int, -1>;
+        tap(IC{}, integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, 1>{}, 0);
+        tap(integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 2>{}, integral_constant<int, 3>{}, 1);
+        tap(integral_constant<int, 3>{}, integral_constant<int, 4>{}, integral_constant<int, 4>{}, integral_constant<int, 5>{}, 2);
+        tap(integral_constant<int, 5>{}, integral_constant<int, 6>{}, integral_constant<int, 6>{}, IC{}, 3);
+        for (int t = 4; t < a.ntaps; ++t) tap(IC{}, IC{}, IC{}, IC{}, t);
+        __syncthreads();
+        pcur ^= 1;
+        stamp();
+      }
     } else
     for (int c = 0; c < a.nchunk; ++c) {
       const bool last_chunk = c + 1 == a.nchunk;
@@ -444,80 +525,105 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
       constexpr int ACT = decltype(act_tag)::value;
       constexpr bool MASK = decltype(mask_tag)::value;
       constexpr bool STATS = decltype(stats_tag)::value;
-      float ssum[STATS ? 4 * FJ : 1], ssq[STATS ? 4 * FJ : 1];
-      if constexpr (STATS) {
-#pragma unroll
-        for (int q = 0; q < 4 * FJ; ++q) ssum[q] = ssq[q] = 0.f;
-      }
+      // lane roles re-derived from an opaque copy: otherwise hipcc computes the epilogue's per-lane offsets once per kernel, finds no free
+      // register across the tap loop of the 256-channel tiles and spills them -- and every scratch reload waits with vmcnt(0), which
+      // also drains the stores in flight (measured: 21 k cycles of epilogue instead of 9 k)
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      const int fr = lane_o & 15, fg = lane_o >> 4;
       bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
       const bf16_t* mask = reinterpret_cast<const bf16_t*>(a.mask);
-      f32x4_t bq[FJ];   // bias of this lane's channel quads
-#pragma unroll
-      for (int j = 0; j < FJ; ++j) {
-        const int n = g.n0 + wn * (16 * FJ) + j * 16 + fg * 4;
-        bq[j] = (a.bias && n < a.Nst) ? *reinterpret_cast<const f32x4_t*>(a.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-      }
       const bool odd = fg & 1;
       float oscale = 1.f;
       if constexpr (FP8) oscale = a.w_scale[0] * (a.in_scale ? a.in_scale[g.b] : 1.f);
+      // The 256-channel tiles walk the pixel groups once per PAIR of channel fragments (JG passes): with 128-144 accumulators live, the
+      // bias quads and statistics of all four fragments at once (48 registers) do not fit beside the next tile's weights in flight
+      // Statistics are summed over groups of 64 (256-row tiles) or 144 (288-row tiles) pixels at either tile width -- HS groups per wave --
+      // and combined in group order: the partials, and with them every result downstream, do not depend on the tile width the
+      // planner picks (it depends on the batch size: G(x)[i] stays bit-identical whatever else is in the batch)
+      constexpr int JG = BN == 256 ? FJ / 2 : 1, JW = FJ / JG;
+      constexpr int HS = (BN == 256 && BM == 256) ? 2 : 1, FH = FI / HS;
 #pragma unroll
-      for (int i = 0; i < FI; ++i) {
-        const int m = g.m0 + wm * (16 * FI) + i * 16 + fr;
-        const bool mok = m < a.M_img;
-        const int mm = mok ? m : a.M_img - 1;
-        const int ho = mm / a.Wo, wo = mm - ho * a.Wo;
-        const int64_t ob = ((int64_t)(g.b * a.out_Hp + ho * a.out_sy + a.out_y0) * a.out_Wp + wo * a.out_sx + a.out_x0) * a.out_C;
-        u32x2_t pk[FJ];
+      for (int jg = 0; jg < JG; ++jg) {
+        const int j0 = jg * JW;
+        f32x4_t bq[JW];   // bias of this lane's channel quads
 #pragma unroll
-        for (int j = 0; j < FJ; ++j) {
-          float v[4];
+        for (int j = 0; j < JW; ++j) {
+          const int n = g.n0 + wn * (16 * FJ) + (j0 + j) * 16 + fg * 4;
+          bq[j] = (a.bias && n < a.Nst) ? *reinterpret_cast<const f32x4_t*>(a.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float t = FP8 ? acc[i][j][e] * oscale + bq[j][e] : acc[i][j][e] + bq[j][e];
-            if constexpr (STATS) { const float tm = mok ? t : 0.f; ssum[4 * j + e] += tm; ssq[4 * j + e] += tm * tm; }
-            v[e] = ACT == GAN_ACT_RELU ? fmaxf(t, 0.f) : ACT == GAN_ACT_LRELU ? (t > 0.f ? t : 0.2f * t) : ACT == GAN_ACT_TANH ? tanhf(t) : t;
+        for (int h = 0; h < HS; ++h) {
+        float ssum[STATS ? 4 * JW : 1], ssq[STATS ? 4 * JW : 1];
+        if constexpr (STATS) {
+#pragma unroll
+          for (int q = 0; q < 4 * JW; ++q) ssum[q] = ssq[q] = 0.f;
+        }
+#pragma unroll
+        for (int i = h * FH; i < (h + 1) * FH; ++i) {
+          if constexpr (BN == 256) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from overlapping pixel groups (it spills)
+          int lf = lane_o;
+          if constexpr (JG > 1) asm volatile("" : "+v"(lf));   // every pass recomputes its addresses from the lane id (shared, they would be spilled between the passes)
+          const int m = g.m0 + wm * (16 * FI) + i * 16 + (lf & 15);
+          const bool mok = m < a.M_img;
+          const int mm = mok ? m : a.M_img - 1;
+          const int ho = mm / a.Wo, wo = mm - ho * a.Wo;
+          const int64_t ob = ((int64_t)(g.b * a.out_Hp + ho * a.out_sy + a.out_y0) * a.out_Wp + wo * a.out_sx + a.out_x0) * a.out_C;
+          u32x2_t pk[JW];
+#pragma unroll
+          for (int j = 0; j < JW; ++j) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float t = FP8 ? acc[i][j0 + j][e] * oscale + bq[j][e] : acc[i][j0 + j][e] + bq[j][e];
+              if constexpr (STATS) { const float tm = mok ? t : 0.f; ssum[4 * j + e] += tm; ssq[4 * j + e] += tm * tm; }
+              v[e] = ACT == GAN_ACT_RELU ? fmaxf(t, 0.f) : ACT == GAN_ACT_LRELU ? (t > 0.f ? t : 0.2f * t) : ACT == GAN_ACT_TANH ? tanhf(t) : t;
+            }
+            if (MASK) {
+              const int n = g.n0 + wn * (16 * FJ) + (j0 + j) * 16 + fg * 4;
+              if (n < a.Nst) {
+                const int64_t mb = ((int64_t)(g.b * a.mask_Hp + ho * a.out_sy + a.mask_y0) * a.mask_Wp + wo * a.out_sx + a.mask_x0) * a.out_C;
+                const u32x2_t mv = *reinterpret_cast<const u32x2_t*>(mask + mb + n);
+                v[0] *= (bf2f((bf16_t)(mv[0] & 0xffff)) > 0.f ? 1.f : 0.2f); v[1] *= (bf2f((bf16_t)(mv[0] >> 16)) > 0.f ? 1.f : 0.2f);
+                v[2] *= (bf2f((bf16_t)(mv[1] & 0xffff)) > 0.f ? 1.f : 0.2f); v[3] *= (bf2f((bf16_t)(mv[1] >> 16)) > 0.f ? 1.f : 0.2f);
+              }
+            }
+            pk[j][0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            pk[j][1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
           }
-          if (MASK) {
-            const int n = g.n0 + wn * (16 * FJ) + j * 16 + fg * 4;
-            if (n < a.Nst) {
-              const int64_t mb = ((int64_t)(g.b * a.mask_Hp + ho * a.out_sy + a.mask_y0) * a.mask_Wp + wo * a.out_sx + a.mask_x0) * a.out_C;
-              const u32x2_t mv = *reinterpret_cast<const u32x2_t*>(mask + mb + n);
-              v[0] *= (bf2f((bf16_t)(mv[0] & 0xffff)) > 0.f ? 1.f : 0.2f); v[1] *= (bf2f((bf16_t)(mv[0] >> 16)) > 0.f ? 1.f : 0.2f);
-              v[2] *= (bf2f((bf16_t)(mv[1] & 0xffff)) > 0.f ? 1.f : 0.2f); v[3] *= (bf2f((bf16_t)(mv[1] >> 16)) > 0.f ? 1.f : 0.2f);
+          // lanes 16 apart hold the same pixel and adjacent channel quads: of each pair of channel tiles even fg keeps the first
+          // and odd fg the second; each sends the quad of the tile it does not keep -> one 16-byte run per lane and tile pair
+#pragma unroll
+          for (int jp = 0; jp < JW / 2; ++jp) {
+            const uint32_t s0 = odd ? pk[2 * jp][0] : pk[2 * jp + 1][0], s1 = odd ? pk[2 * jp][1] : pk[2 * jp + 1][1];
+            const uint32_t r0 = (uint32_t)__shfl_xor((int)s0, 16, 64), r1 = (uint32_t)__shfl_xor((int)s1, 16, 64);
+            u32x4_t st;
+            if (!odd) { st[0] = pk[2 * jp][0]; st[1] = pk[2 * jp][1]; st[2] = r0; st[3] = r1; }
+            else      { st[0] = r0; st[1] = r1; st[2] = pk[2 * jp + 1][0]; st[3] = pk[2 * jp + 1][1]; }
+            const int nst = g.n0 + wn * (16 * FJ) + (j0 + 2 * jp + (odd ? 1 : 0)) * 16 + (fg & 2) * 4;
+            if (mok && nst < a.Nst) *reinterpret_cast<u32x4_t*>(out + ob + nst) = st;
+          }
+        }
+        if constexpr (STATS) {
+          // InstanceNorm partials of this tile: over the 16 pixel lanes of a lane group, then over the pixel-split waves in a
+          // fixed order (deterministic: no atomics), one float2 per channel to stats[b][m-tile][n]
+          // row (16-lane) all-reduce with DPP modifiers on the adds -- vector ALU only; __shfl_xor lowers to ds_bpermute and 256 of
+          // those per wave cost 8 us per launch, as much as the statistics pass they replace
+#pragma unroll
+          for (int q = 0; q < 4 * JW; ++q) { ssum[q] = row16_sum(ssum[q]); ssq[q] = row16_sum(ssq[q]); }
+          if (fr == 0) {
+#pragma unroll
+            for (int q = 0; q < 4 * JW; ++q) {
+              const int ch = (j0 + (q >> 2)) * 16 + fg * 4 + (q & 3);           // channel inside this wave's 16*FJ
+              *reinterpret_cast<float2*>(stsh + ((((wm * HS + h) * WGN + wn) * (16 * FJ) + ch) << 1)) = make_float2(ssum[q], ssq[q]);
             }
           }
-          pk[j][0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-          pk[j][1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
         }
-        // lanes 16 apart hold the same pixel and adjacent channel quads: of each pair of channel tiles even fg keeps the first
-        // and odd fg the second; each sends the quad of the tile it does not keep -> one 16-byte run per lane and tile pair
-#pragma unroll
-        for (int jp = 0; jp < FJ / 2; ++jp) {
-          const uint32_t s0 = odd ? pk[2 * jp][0] : pk[2 * jp + 1][0], s1 = odd ? pk[2 * jp][1] : pk[2 * jp + 1][1];
-          const uint32_t r0 = (uint32_t)__shfl_xor((int)s0, 16, 64), r1 = (uint32_t)__shfl_xor((int)s1, 16, 64);
-          u32x4_t st;
-          if (!odd) { st[0] = pk[2 * jp][0]; st[1] = pk[2 * jp][1]; st[2] = r0; st[3] = r1; }
-          else      { st[0] = r0; st[1] = r1; st[2] = pk[2 * jp + 1][0]; st[3] = pk[2 * jp + 1][1]; }
-          const int nst = g.n0 + wn * (16 * FJ) + (2 * jp + (odd ? 1 : 0)) * 16 + (fg & 2) * 4;
-          if (mok && nst < a.Nst) *reinterpret_cast<u32x4_t*>(out + ob + nst) = st;
         }
       }
       if constexpr (STATS) {
-        // InstanceNorm partials of this tile: over the 16 pixel lanes of a lane group, then over the pixel-split waves in a
-        // fixed order (deterministic: no atomics), one float2 per channel to stats[b][m-tile][n]
-        // row (16-lane) all-reduce with DPP modifiers on the adds -- vector ALU only; __shfl_xor lowers to ds_bpermute and 256 of
-        // those per wave cost 8 us per launch, as much as the statistics pass they replace
-#pragma unroll
-        for (int q = 0; q < 4 * FJ; ++q) { ssum[q] = row16_sum(ssum[q]); ssq[q] = row16_sum(ssq[q]); }
-        if (fr == 0) {
-#pragma unroll
-          for (int q = 0; q < 4 * FJ; ++q) {
-            const int ch = (q >> 2) * 16 + fg * 4 + (q & 3);           // channel inside this wave's 16*FJ
-            *reinterpret_cast<float2*>(stsh + ((wave * (16 * FJ) + ch) << 1)) = make_float2(ssum[q], ssq[q]);
-          }
-        }
         __syncthreads();
-        constexpr int WM = 8 / WGN;
+        constexpr int WM = 8 / WGN * HS;
         if (tid < BN) {
           const int cwn = tid / (16 * FJ), cch = tid % (16 * FJ);
           float2 tot = make_float2(0.f, 0.f);
@@ -548,8 +654,8 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
   }
 }
 
-template <int BM, int WGN, int NT, bool FP8 = false, int NS = 7>
-__global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) { conv_patch_body<BM, WGN, NT, FP8, NS>(a); }
+template <int BM, int WGN, int NT, bool FP8 = false, int NS = 7, int BN = 128>
+__global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) { conv_patch_body<BM, WGN, NT, FP8, NS, BN>(a); }
 // The fp8 variants take all 256 registers (two 32-byte weight sets, one activation set, 64 accumulators and the compiler's scheduling
 // slack), so nothing of another stream runs beside them.  Capping them (`amdgpu_num_vgpr(108)`: on gfx90a+ the request is doubled, a
 // request of 216 is silently dropped) was measured: 216 registers = 304 bytes of scratch per lane inside the tap loop, 3x slower.
@@ -568,9 +674,26 @@ static int patch_span(const gan_conv_desc* d, int BM) {
   return (rows - 1) * d->in_sx + wraps * (jump > 0 ? jump : 0) + maxtap + 1;
 }
 
-// tile height: the planner's choice if the descriptor carries one, otherwise the one that needs the fewest CU-rounds x rows
+// tile width for a tile height: the planner's choice if the descriptor carries one; otherwise 256 channels when the layer's Cout is a
+// multiple of it and the 256-wide tiles still fill the chip (bf16, >= 4 taps, maps up to 64 pixels wide: the 7-slice buffers), else 128.
+// GAN_PATCH_BN = 128 | 256 forces one wherever the layer is eligible (a tuning / test aid that only the planning call reads).
+static int patch_bn(const gan_conv_desc* d, int BM, bool planning = false) {
+  const bool eligible = d->dtype == GAN_BF16 && d->Nw % 256 == 0 && d->Nst % 256 == 0 && d->ntaps >= 4 && patch_span(d, BM) <= RMAX;
+  if (!eligible) return 128;
+  if (!planning && (d->tile_cols == 128 || d->tile_cols == 256)) return d->tile_cols;
+  if (planning) {
+    const char* e = getenv("GAN_PATCH_BN");
+    const int forced = e ? atoi(e) : 0;
+    if (forced == 128 || forced == 256) return forced;
+  }
+  const int64_t tiles = (int64_t)d->B * ((d->Ho * d->Wo + BM - 1) / BM) * (d->Nst / 256);
+  return tiles >= 192 ? 256 : 128;
+}
+
+// tile height: the planner's choice if the descriptor carries one, otherwise the one that needs the fewest CU-rounds x tile area
 // (GAN_PATCH_BM forces one; a tuning aid that only the planning call gan_conv_patch_tile_rows reads)
 static int patch_tile_rows(const gan_conv_desc* d, bool planning = false) {
+  constexpr int BN = 128;
   const int M_img = d->Ho * d->Wo, ncu = 256;
   int BM = 0, forced = 0;
   int64_t best = 0;
@@ -580,8 +703,9 @@ static int patch_tile_rows(const gan_conv_desc* d, bool planning = false) {
   for (int cand : {256, 288}) {
     const int lim = cand == 256 ? RMAX_WIDE : RMAX;      // the 9-slice buffers exist for the 256-row tile only
     if (patch_span(d, cand) > lim || (forced && forced != cand && patch_span(d, forced) <= (forced == 256 ? RMAX_WIDE : RMAX))) continue;
-    const int64_t tiles = (int64_t)d->B * ((M_img + cand - 1) / cand) * ((d->Nst + BN - 1) / BN);
-    const int64_t cost = ((tiles + ncu - 1) / ncu) * cand;
+    const int bn = patch_bn(d, cand, planning);
+    const int64_t tiles = (int64_t)d->B * ((M_img + cand - 1) / cand) * ((d->Nst + bn - 1) / bn);
+    const int64_t cost = ((tiles + ncu - 1) / ncu) * cand * (bn / BN);
     if (!BM || cost < best) { BM = cand; best = cost; }
   }
   return BM;
@@ -593,6 +717,7 @@ extern "C" int gan_conv_patch_ok(const gan_conv_desc* d) {
   static int disabled = -1;
   if (disabled < 0) { const char* e = getenv("GAN_NO_PATCH"); disabled = (e && atoi(e)) ? 1 : 0; }
   if (disabled || !d) return 0;
+  constexpr int BN = 128;
   if (d->mask && d->act != GAN_ACT_NONE) return 0;   // the masked epilogue is specialised for act = none
   const bool fp8 = d->dtype == GAN_FP8;
   const int slots = fp8 ? d->Cin / 2 : d->Cin;             // 2-byte slots per pixel (fp8: two channels per slot)
@@ -613,6 +738,10 @@ extern "C" int gan_conv_patch_tile_rows(const gan_conv_desc* d) {
   return gan_conv_patch_ok(d) ? patch_tile_rows(d, true) : 0;
 }
 
+extern "C" int gan_conv_patch_tile_cols(const gan_conv_desc* d) {
+  return gan_conv_patch_ok(d) ? patch_bn(d, patch_tile_rows(d), true) : 0;
+}
+
 // InstanceNorm partials per image the range-patch kernel writes to d->stats ([B][parts][out_C][2]); 0: this descriptor cannot fuse them
 int gan_conv_win7_stats_parts(const gan_conv_desc* d);
 extern "C" int gan_conv_stats_parts(const gan_conv_desc* d) {
@@ -628,6 +757,7 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   const int M_img = d->Ho * d->Wo;
   const int ncu = 256;
   const int BM = patch_tile_rows(d);
+  const int BN = patch_bn(d, BM);
   a.in = (const char*)d->in; a.w = (const char*)d->w; a.bias = d->bias; a.out = (char*)d->out; a.mask = (const char*)d->mask; a.tapoff = d->tapoff;
   a.B = d->B; a.M_img = M_img; a.Wo = d->Wo; a.MT_img = (M_img + BM - 1) / BM; a.NTILES = (d->Nst + BN - 1) / BN;
   a.tiles = a.B * a.MT_img * a.NTILES;
@@ -656,7 +786,8 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
     auto raise = [](const void* f, int bytes) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; };
     if (!raise((const void*)conv_patch_kernel<256, 2, 0>, lds_bytes(7)) || !raise((const void*)conv_patch_kernel<288, 4, 0>, lds_bytes(7)) ||
         !raise((const void*)conv_patch_kernel<256, 2, 9>, lds_bytes(7)) || !raise((const void*)conv_patch_fp8_kernel, lds_bytes(7)) ||
-        !raise((const void*)conv_patch_kernel<256, 2, 0, false, 9>, lds_bytes(9)) || !raise((const void*)conv_patch_fp8_wide_kernel, lds_bytes(9)))
+        !raise((const void*)conv_patch_kernel<256, 2, 0, false, 9>, lds_bytes(9)) || !raise((const void*)conv_patch_fp8_wide_kernel, lds_bytes(9)) ||
+        !raise((const void*)conv_patch_kernel<256, 4, 0, false, 7, 256>, lds_bytes(7)) || !raise((const void*)conv_patch_kernel<288, 4, 0, false, 7, 256>, lds_bytes(7)))
       return gan_set_error(-2, "conv_patch: cannot raise the dynamic LDS limit to %d bytes", lds_bytes(9));
     attr_devs.fetch_or(dev_bit, std::memory_order_release);
   }
@@ -668,6 +799,9 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   if (fp8) {
     if (wide) hipLaunchKernelGGL(conv_patch_fp8_wide_kernel, dim3(grid), dim3(NTHR), lds_bytes(9), s, a);
     else hipLaunchKernelGGL(conv_patch_fp8_kernel, dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
+  } else if (BN == 256) {
+    if (BM == 256) hipLaunchKernelGGL((conv_patch_kernel<256, 4, 0, false, 7, 256>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
+    else hipLaunchKernelGGL((conv_patch_kernel<288, 4, 0, false, 7, 256>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
   } else if (BM == 256) {
     if (wide) hipLaunchKernelGGL((conv_patch_kernel<256, 2, 0, false, 9>), dim3(grid), dim3(NTHR), lds_bytes(9), s, a);
     else if (st9) hipLaunchKernelGGL((conv_patch_kernel<256, 2, 9>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);

@@ -95,6 +95,7 @@ class ConvCall:
     max_tapoff: int = 0
     w_frag: bool = False      # w is the fragment-major copy (range-patch kernel)
     tile_rows: int = 0        # range-patch kernel: pixels per tile, fixed at planning time (HipOps.conv_patch_tile_rows)
+    tile_cols: int = 0        # ... and output channels per tile (HipOps.conv_patch_tile_cols, after tile_rows)
     stats: Optional[torch.Tensor] = None   # InstanceNorm partials written by the epilogue (see HipOps.conv_stats_parts)
     win7: Optional[tuple] = None           # (ty0, tx0): run by the 7x7 window kernel, taps row-major from that position (w_layout 2)
     w_scale: Optional[torch.Tensor] = None  # fp8 operands: device float, dequantisation scale of the weight copy
@@ -281,7 +282,7 @@ class HipOps:
         d.stats = c.stats.data_ptr() if c.stats is not None else None
         d.max_tapoff = c.max_tapoff
         d.w_layout = 1 if c.w_frag else 0
-        d.tile_rows = c.tile_rows
+        d.tile_rows, d.tile_cols = c.tile_rows, c.tile_cols
         d.w_scale = c.w_scale.data_ptr() if c.w_scale is not None else None
         d.in_scale = c.in_scale.data_ptr() if c.in_scale is not None else None
         if c.win7 is not None:
@@ -297,6 +298,10 @@ class HipOps:
     def conv_patch_tile_rows(self, c: ConvCall) -> int:
         """Pixels per tile the range-patch kernel uses for this call (0: not eligible); planned once, carried in the descriptor."""
         return int(self.lib.gan_conv_patch_tile_rows(C.byref(self._conv_desc(c))))
+
+    def conv_patch_tile_cols(self, c: ConvCall) -> int:
+        """Output channels per tile (128 | 256) for the call's tile_rows; planned once, carried in the descriptor."""
+        return int(self.lib.gan_conv_patch_tile_cols(C.byref(self._conv_desc(c))))
 
     def conv_win7_ok(self, c: ConvCall, ty0: int, tx0: int) -> bool:
         """True if the 7x7 window kernel takes this call with its 49 row-major taps starting at (ty0, tx0)."""

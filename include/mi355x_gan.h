@@ -72,7 +72,8 @@ typedef struct gan_conv_desc {
   int32_t win_ty0, win_tx0;      /* w_layout 2: tapoff[t] = ((win_ty0 + t/7) * in_Wp + win_tx0 + t%7) * Cin, t = 0..48 */
   int32_t tile_rows;             /* w_layout 1: output pixels per tile (256 or 288), fixed by the planner with gan_conv_patch_tile_rows so
                                     that the launch and the partial count of `stats` (gan_conv_stats_parts) agree; 0: chosen at launch */
-  int32_t _pad;
+  int32_t tile_cols;             /* w_layout 1: output channels per tile (128 or 256), fixed by the planner with gan_conv_patch_tile_cols
+                                    AFTER tile_rows is set; 0: chosen at launch */
   /* dtype GAN_FP8 (range-patch kernel only, w_layout 1): `in` and `w` hold e4m3 bytes, `out` / `mask` / `bias` are as for GAN_BF16
    * (the result is bf16).  result = act(acc * w_scale[0] * (in_scale ? in_scale[b] : 1) + bias): the dequantisation scales of the
    * weight copy (gan_weight_scale_batch) and of image b of the input copy (gan_quantize_fp8), both device pointers. */
@@ -113,6 +114,11 @@ int gan_conv_patch_ok(const gan_conv_desc* d);
 /* pixels per tile the range-patch kernel would choose for this descriptor (256 or 288: the one with the fewest CU-rounds x rows; the
  * tuning variable GAN_PATCH_BM is read HERE, at planning time, never at launch); 0 if the descriptor does not qualify */
 int gan_conv_patch_tile_rows(const gan_conv_desc* d);
+/* output channels per tile for the descriptor's tile_rows: 256 (the whole Cout of the residual 256 -> 256 layers: one slab staging and
+ * one epilogue per pixel tile, 32-36 MFMAs per k-step and wave) when Nst % 256 == 0, the layer has >= 4 taps, its maps are at most 64
+ * pixels wide and the 256-wide tiles still fill the chip (>= 192 of them), else 128.  GAN_PATCH_BN = 128 | 256 (read here, at planning
+ * time) forces one wherever the layer is eligible; 0 if the descriptor does not qualify for the range-patch kernel */
+int gan_conv_patch_tile_cols(const gan_conv_desc* d);
 /* 1 if the descriptor qualifies for a 7x7 window kernel (bf16, stride 1, 49 row-major taps located by win_ty0/win_tx0, act none or
  * tanh, no mask / stats): Cin = 64, Nw = 16, Nst = out_C = 8 (the 64 -> 3 channel layers) or Cin = 8, Nw = Nst = out_C = 64 with the
  * tap list padded to >= 52 (the 3 -> 64 channel layers) */

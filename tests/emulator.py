@@ -126,6 +126,10 @@ class EmuOps:
         """Statement of gan_conv_patch_tile_rows: any non-zero value for a qualifying call (the emulator has no tiles)."""
         return 256 if self.conv_patch_ok(c) else 0
 
+    def conv_patch_tile_cols(self, c):
+        """Statement of gan_conv_patch_tile_cols: any non-zero value for a qualifying call."""
+        return 128 if self.conv_patch_ok(c) else 0
+
     def conv_win7_ok(self, c, ty0, tx0):
         """Mirror of gan_conv_win7_ok (the emulator computes every call the same way; the flag only has to agree with the library)."""
         to3 = c.Cin == 64 and c.ntaps == 49 and c.Nw == 16 and c.Nst == 8 and c.out.C == 8

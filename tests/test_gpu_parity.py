@@ -31,6 +31,27 @@ def test_conv_geometry_hip_tile288(geom, monkeypatch):
     cases.run_conv_geometry(hip_ctx(BF16), geom, BF16, B=3)
 
 
+@pytest.mark.parametrize("bm", ["256", "288"])
+@pytest.mark.parametrize("geom", [g for g in cases.GEOMS if g[1] % 256 == 0 and g[3] == 1 and not g[5]])
+def test_conv_geometry_hip_tile_cols256(geom, bm, monkeypatch):
+    """The 256-channel tiles of the range-patch kernel (whole Cout of the residual layers per tile; chosen on launches of >= 192 such
+    tiles) at both tile heights: forced here on the small geometries (3x3 256->256 forward / reflect-padded input gradient, 4x4 256->512)."""
+    monkeypatch.setenv("GAN_PATCH_BN", "256")
+    monkeypatch.setenv("GAN_PATCH_BM", bm)
+    ctx = hip_ctx(BF16)
+    cases.run_conv_geometry(ctx, geom, BF16, B=3)
+    cin, cout, k = geom[0], geom[1], geom[2]
+    from gan_variant_research_amd.runtime import ConvCall  # noqa: F401  (the planner really chose the wide tile)
+    from gan_variant_research_amd.convplan import ConvLayer
+    w = torch.zeros(cout, cin, k, k, device=DEV)
+    layer = ConvLayer(ctx, w, torch.zeros(cout, device=DEV), torch.zeros_like(w), torch.zeros(cout, device=DEV), k, 1, geom[4], False)
+    H = geom[6]
+    Ho = H + 2 * geom[4] - k + 1
+    x, y = ctx.view(3, H, H, cin, max(geom[4], 1)), ctx.view(3, Ho, Ho, cout, 0)
+    layer.fwd(x, y)
+    assert layer.last_call.tile_cols == 256 and layer.last_call.tile_rows == int(bm)
+
+
 @pytest.mark.parametrize("geom", [g for g in cases.GEOMS if g[2] == 7 and max(g[0], g[1]) == 64])
 def test_conv_7x7_window_kernel_is_taken(geom):
     """The 64 <-> 3 channel 7x7 layers run on the two window kernels in bf16 (64->3: output conv forward, first conv's input gradient;
@@ -562,13 +583,15 @@ def test_module_step_hip(monkeypatch):
     module_step_cases(DEV, 1e-3, 2e-3)
 
 
+@pytest.mark.parametrize("bn", ["128", "256"])
 @pytest.mark.parametrize("bm", ["256", "288"])
 @pytest.mark.parametrize("H", [16, 20])
-def test_conv_fused_instance_norm_statistics(bm, H, monkeypatch):
+def test_conv_fused_instance_norm_statistics(bm, H, bn, monkeypatch):
     """Per-tile (sum, sum of squares) written by the range-patch epilogue + gan_in_stats_from_parts == InstanceNorm statistics of the
-    convolution result; both tile heights, a map with a partial last tile (H=20: 400 pixels)."""
+    convolution result; both tile heights and widths, a map with a partial last tile (H=20: 400 pixels)."""
     from gan_variant_research_amd.convplan import ConvLayer
     monkeypatch.setenv("GAN_PATCH_BM", bm)
+    monkeypatch.setenv("GAN_PATCH_BN", bn)
     B, Cc = 3, 256
     tw = Twin(BF16, seed=11)
     xc, xg = tw.view(B, H, H, Cc, 1)

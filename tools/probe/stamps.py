@@ -1,29 +1,42 @@
+"""In-kernel s_memtime stamps of the range-patch convolution (GAN_PATCH_STAMPS): cycles per phase of wave 0 of every block.
+usage: stamps.py [fwd|dgrad] [B]     (GAN_PATCH_BN=128 in the environment: the 128-channel tiles)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
 dev = torch.device("cuda:0")
 buf = torch.zeros(256 * 32, dtype=torch.int64, device=dev)
-os.environ["GAN_PATCH_STAMPS"] = str(buf.data_ptr() + (int(sys.argv[1]) if len(sys.argv) > 1 else 0))
+os.environ["GAN_PATCH_STAMPS"] = str(buf.data_ptr())
+mode = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 from gan_variant_research_amd import BF16
 from gan_variant_research_amd.convplan import ConvLayer
 from gan_variant_research_amd.runtime import Ctx, HipOps
 ctx = Ctx(HipOps(dev), dev, BF16)
-B = 16
 w = torch.randn(256, 256, 3, 3, device=dev) * 0.05
 b = torch.zeros(256, device=dev)
 layer = ConvLayer(ctx, w, b, torch.zeros_like(w), torch.zeros_like(b), 3, 1, 1)
-x = ctx.view(B, 64, 64, 256, 1); x.t.normal_()
-y = ctx.view(B, 64, 64, 256, 0)
-ops = layer.fwd(x, y)
 for o in layer.repack_ops(): o()
-for _ in range(5):
+if mode == "fwd":
+    x = ctx.view(B, 64, 64, 256, 1); x.t.normal_()
+    y = ctx.view(B, 64, 64, 256, 0)
+    ops = layer.fwd(x, y)
+else:
+    dy = ctx.view(B, 64, 64, 256, 2); dy.t.normal_()
+    dx = ctx.view(B, 64, 64, 256, 1)
+    ops = layer.dgrad(dy, dx, padded_domain=True)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for _ in range(20):
     for o in ops: o()
+e0.record()
+for _ in range(20):
+    for o in ops: o()
+e1.record()
 torch.cuda.synchronize()
-st = buf.view(256, 32).cpu()
-import numpy as np
-s = st.numpy().astype(np.int64)
-d = np.diff(s[:, :12], axis=1)   # stamps: start, after prologue, 4 slabs, epilogue, 4 slabs, epilogue
-names = ["prologue", "slab0", "slab1", "slab2", "slab3", "epilogue", "slab0'", "slab1'", "slab2'", "slab3'", "epilogue'"]
-print("s_memtime ticks (100 MHz constant clock?) median over 256 blocks; total", np.median(s[:, 11] - s[:, 0]))
-for n, col in zip(names, d.T):
-    print(f"{n:10s} median {np.median(col):9.0f}  min {col.min():9.0f}  max {col.max():9.0f}")
-print("block start spread:", s[:, 0].max() - s[:, 0].min(), " end spread:", s[:, 11].max() - s[:, 11].min())
+print(f"{mode} B={B}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per launch (with the stamp code active)")
+s = buf.view(256, 32).cpu().numpy().astype(np.int64)
+n = int((s[0] != 0).sum())
+d = np.diff(s[:, :n], axis=1)
+print(f"{n} stamps per block; wave 0 lifetime median {np.median(s[:, n - 1] - s[:, 0]):.0f} cycles")
+for i, col in enumerate(d.T):
+    print(f"  phase {i:2d} median {np.median(col):9.0f}  min {col.min():9.0f}  max {col.max():9.0f}")
+print("block start spread:", s[:, 0].max() - s[:, 0].min(), " end spread:", s[:, n - 1].max() - s[:, n - 1].min())
