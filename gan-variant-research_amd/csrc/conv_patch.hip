@@ -32,12 +32,14 @@ namespace {
 struct PatchArgs {
   const char* in; const char* w; const float* bias; char* out; const char* mask; const int32_t* tapoff;
   int B, M_img, Wo, MT_img, NTILES, tiles;
+  uint32_t wo_magic;            // ceil(2^32 / Wo): m / Wo == umulhi(m, wo_magic) for every output pixel index m of one image (host-checked)
   int Cin, nchunk, ntaps, KB;                             // KB = Ktot/32 fragment blocks per 16-row weight tile
   int in_Hp, in_Wp, in_y0, in_x0, in_sy, in_sx, in_pix;   // in_pix: pixels in the whole input tensor
   int out_Hp, out_Wp, out_C, out_y0, out_x0, out_sy, out_sx;
   int Nst, act;
   int mask_Hp, mask_Wp, mask_y0, mask_x0;
   int w_bytes;
+  uint32_t out_bytes, mask_bytes;   // whole-tensor sizes: the epilogue addresses `out` / `mask` through buffer descriptors with 32-bit offsets
   int tapdiv;                   // tapoff[] / tapdiv = pixel offset of a tap (the operand's REAL channel count; Cin counts 2-byte slots)
   const float* w_scale; const float* in_scale;   // FP8: dequantisation scales (weights: one float; input: per image or NULL)
   float* stats;                 // optional per-tile InstanceNorm partials [B][MT_img][out_C][2] (sum, sum of squares), plain stores
@@ -74,7 +76,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 __device__ __forceinline__ int pixbase(const PatchArgs& a, int b, int m) {
-  const int ho = m / a.Wo, wo = m - ho * a.Wo;
+  const int ho = (int)__umulhi((uint32_t)m, a.wo_magic), wo = m - ho * a.Wo;
   return (b * a.in_Hp + ho * a.in_sy + a.in_y0) * a.in_Wp + wo * a.in_sx + a.in_x0;
 }
 template <int BM, int BN>
@@ -531,9 +533,11 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
       int lane_o = lane;
       asm volatile("" : "+v"(lane_o));
       const int fr = lane_o & 15, fg = lane_o >> 4;
-      bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
-      const bf16_t* mask = reinterpret_cast<const bf16_t*>(a.mask);
-      const bool odd = fg & 1;
+      // results leave through a buffer descriptor: 32-bit offsets (the 64-bit address arithmetic per store was a fifth of the epilogue's
+      // instructions and its temporaries spilled beside 144 accumulators), and a store outside the tile's real rows / channels is sent
+      // to offset 2^32 - 16, which the range check drops -- no branch around the stores
+      const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.mask, 0, a.mask_bytes, 0x00020000);
       float oscale = 1.f;
       if constexpr (FP8) oscale = a.w_scale[0] * (a.in_scale ? a.in_scale[g.b] : 1.f);
       // The 256-channel tiles walk the pixel groups once per PAIR of channel fragments (JG passes): with 128-144 accumulators live, the
@@ -561,14 +565,14 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
         }
 #pragma unroll
         for (int i = h * FH; i < (h + 1) * FH; ++i) {
-          if constexpr (BN == 256) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from overlapping pixel groups (it spills)
+          __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from overlapping pixel groups (registers: it spills on the wide tiles, and the narrow ones must leave room for the other streams)
           int lf = lane_o;
           if constexpr (JG > 1) asm volatile("" : "+v"(lf));   // every pass recomputes its addresses from the lane id (shared, they would be spilled between the passes)
           const int m = g.m0 + wm * (16 * FI) + i * 16 + (lf & 15);
           const bool mok = m < a.M_img;
           const int mm = mok ? m : a.M_img - 1;
-          const int ho = mm / a.Wo, wo = mm - ho * a.Wo;
-          const int64_t ob = ((int64_t)(g.b * a.out_Hp + ho * a.out_sy + a.out_y0) * a.out_Wp + wo * a.out_sx + a.out_x0) * a.out_C;
+          const int ho = (int)__umulhi((uint32_t)mm, a.wo_magic), wo = mm - ho * a.Wo;
+          const uint32_t ob = (uint32_t)(((g.b * a.out_Hp + ho * a.out_sy + a.out_y0) * a.out_Wp + wo * a.out_sx + a.out_x0) * a.out_C);   // element offset
           u32x2_t pk[JW];
 #pragma unroll
           for (int j = 0; j < JW; ++j) {
@@ -582,8 +586,8 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
             if (MASK) {
               const int n = g.n0 + wn * (16 * FJ) + (j0 + j) * 16 + fg * 4;
               if (n < a.Nst) {
-                const int64_t mb = ((int64_t)(g.b * a.mask_Hp + ho * a.out_sy + a.mask_y0) * a.mask_Wp + wo * a.out_sx + a.mask_x0) * a.out_C;
-                const u32x2_t mv = *reinterpret_cast<const u32x2_t*>(mask + mb + n);
+                const uint32_t mb = (uint32_t)(((g.b * a.mask_Hp + ho * a.out_sy + a.mask_y0) * a.mask_Wp + wo * a.out_sx + a.mask_x0) * a.out_C);
+                const u32x2_t mv = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(mrsrc, (int)((mb + (uint32_t)n) * 2u), 0, 0));
                 v[0] *= (bf2f((bf16_t)(mv[0] & 0xffff)) > 0.f ? 1.f : 0.2f); v[1] *= (bf2f((bf16_t)(mv[0] >> 16)) > 0.f ? 1.f : 0.2f);
                 v[2] *= (bf2f((bf16_t)(mv[1] & 0xffff)) > 0.f ? 1.f : 0.2f); v[3] *= (bf2f((bf16_t)(mv[1] >> 16)) > 0.f ? 1.f : 0.2f);
               }
@@ -595,13 +599,16 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
           // and odd fg the second; each sends the quad of the tile it does not keep -> one 16-byte run per lane and tile pair
 #pragma unroll
           for (int jp = 0; jp < JW / 2; ++jp) {
-            const uint32_t s0 = odd ? pk[2 * jp][0] : pk[2 * jp + 1][0], s1 = odd ? pk[2 * jp][1] : pk[2 * jp + 1][1];
-            const uint32_t r0 = (uint32_t)__shfl_xor((int)s0, 16, 64), r1 = (uint32_t)__shfl_xor((int)s1, 16, 64);
-            u32x4_t st;
-            if (!odd) { st[0] = pk[2 * jp][0]; st[1] = pk[2 * jp][1]; st[2] = r0; st[3] = r1; }
-            else      { st[0] = r0; st[1] = r1; st[2] = pk[2 * jp + 1][0]; st[3] = pk[2 * jp + 1][1]; }
-            const int nst = g.n0 + wn * (16 * FJ) + (j0 + 2 * jp + (odd ? 1 : 0)) * 16 + (fg & 2) * 4;
-            if (mok && nst < a.Nst) *reinterpret_cast<u32x4_t*>(out + ob + nst) = st;
+            // v_permlane16_swap(X, Y): lanes of the even 16-lane rows end with (own X, partner's X), lanes of the odd rows with (partner's Y,
+            // own Y) -- the exchange and the selection in two vector instructions (probed: tools/probe/permlane_swap.hip); the former
+            // __shfl_xor pair was two ds_bpermute round trips through the LDS pipe plus four selects
+            const auto ra = __builtin_amdgcn_permlane16_swap(pk[2 * jp][0], pk[2 * jp + 1][0], false, false);
+            const auto rb = __builtin_amdgcn_permlane16_swap(pk[2 * jp][1], pk[2 * jp + 1][1], false, false);
+            const u32x4_t st = {ra[0], rb[0], ra[1], rb[1]};
+            const int fgl = JG > 1 ? lf >> 4 : fg;   // 256-channel tiles: from the opaque lane id (a hoisted 64-bit store base would be spilled and reloaded per store)
+            const int nst = g.n0 + wn * (16 * FJ) + (j0 + 2 * jp + (fgl & 1)) * 16 + (fgl & 2) * 4;
+            const uint32_t off = (mok && nst < a.Nst) ? (ob + (uint32_t)nst) * 2u : 0xfffffff0u;
+            __builtin_amdgcn_raw_buffer_store_b128(st, orsrc, (int)off, 0, 0);
           }
         }
         if constexpr (STATS) {
@@ -724,6 +731,10 @@ extern "C" int gan_conv_patch_ok(const gan_conv_desc* d) {
   if ((d->dtype != GAN_BF16 && !fp8) || slots < 64 || slots % 64 != 0 || d->Nw % BN != 0 || d->Nst % 8 != 0 || d->out_C % 8 != 0) return 0;
   if (fp8 && (d->mask || !d->w_scale || patch_span(d, 256) > RMAX_WIDE)) return 0;   // fp8: 256-row tile, plain epilogue
   if (d->max_tapoff <= 0 || d->ntaps < 1) return 0;
+  // 32-bit byte offsets into the input, output and mask tensors
+  const int64_t lim = (1ll << 32) - 4096;
+  if ((int64_t)d->B * d->in_Hp * d->in_Wp * d->Cin * 2 >= lim || (int64_t)d->B * d->out_Hp * d->out_Wp * d->out_C * 2 >= lim ||
+      (d->mask && (int64_t)d->B * d->mask_Hp * d->mask_Wp * d->out_C * 2 >= lim)) return 0;
   if (!(patch_span(d, 256) <= RMAX_WIDE || patch_span(d, 288) <= RMAX)) return 0;
   // tile utilisation: a map of 324 pixels (18x18 input-gradient domain of a 16x16 layer) fills 63 % of two 256-row tiles -- the
   // generic kernel's 128-row tiles waste less there (Basic_GAN at 64x64: +5 % with it)
@@ -759,6 +770,9 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   const int BM = patch_tile_rows(d);
   const int BN = patch_bn(d, BM);
   a.in = (const char*)d->in; a.w = (const char*)d->w; a.bias = d->bias; a.out = (char*)d->out; a.mask = (const char*)d->mask; a.tapoff = d->tapoff;
+  // m / Wo by multiplication: with magic = ceil(2^32 / Wo) the quotient is exact while m * (magic * Wo - 2^32) < 2^32, i.e. for m * Wo < 2^32
+  if ((int64_t)(M_img + 288) * d->Wo >= (1ll << 32) || d->Wo < 1) return gan_set_error(-1, "conv_patch: map too large for the index arithmetic");
+  a.wo_magic = d->Wo == 1 ? 0xffffffffu : (uint32_t)(((1ull << 32) + d->Wo - 1) / d->Wo);
   a.B = d->B; a.M_img = M_img; a.Wo = d->Wo; a.MT_img = (M_img + BM - 1) / BM; a.NTILES = (d->Nst + BN - 1) / BN;
   a.tiles = a.B * a.MT_img * a.NTILES;
   const bool fp8 = d->dtype == GAN_FP8;
@@ -766,6 +780,8 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   a.tapdiv = d->Cin; a.w_scale = d->w_scale; a.in_scale = d->in_scale;
   a.nchunk = a.Cin / 64; a.ntaps = d->ntaps; a.KB = d->ntaps * a.Cin / 32;
   a.w_bytes = d->Nw * d->ntaps * a.Cin * 2;
+  a.out_bytes = (uint32_t)((int64_t)d->B * d->out_Hp * d->out_Wp * d->out_C * 2);
+  a.mask_bytes = d->mask ? (uint32_t)((int64_t)d->B * d->mask_Hp * d->mask_Wp * d->out_C * 2) : 0;
   a.in_Hp = d->in_Hp; a.in_Wp = d->in_Wp; a.in_y0 = d->in_y0; a.in_x0 = d->in_x0; a.in_sy = d->in_sy; a.in_sx = d->in_sx;
   a.in_pix = d->B * d->in_Hp * d->in_Wp;
   a.out_Hp = d->out_Hp; a.out_Wp = d->out_Wp; a.out_C = d->out_C; a.out_y0 = d->out_y0; a.out_x0 = d->out_x0; a.out_sy = d->out_sy; a.out_sx = d->out_sx;
