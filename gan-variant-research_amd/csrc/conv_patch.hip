@@ -385,7 +385,10 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
       // every join): the 7 slices of the next slab ride on the first 8 k-steps, which are unrolled with their slice numbers as
       // constants (the descriptor has >= 4 taps); after the block's last slab the staging re-reads the current tile into the idle buffer.
       // Measured on the 3x3 256->256 layer, B = 16 (s_memtime, cycles per 64-channel slab; MFMA alone 18.4 k / 20.7 k): 256 rows 24.1 k,
-      // 288 rows 27.3 k = 76 % (the 128-channel tiles: 69-73 %) and half the epilogues; forward 65.6 -> 60.6 us, input gradient 75.7 -> 68.0 us.
+      // 288 rows 27.3 k = 76 % (the 128-channel tiles: 69-73 %) and half the epilogues; forward 65.6 -> 58.4 us, input gradient 75.7 -> 64.5 us.
+      // Where the other 5.8 k cycles of a slab go (each fetch class compiled out in turn, results wrong, timing only): activation
+      // re-reads 2.8 k (LDS latency: 8 MFMAs of cover, a second register set does not fit), weight fetches 1.8 k, staging 0.5 k,
+      // barrier + first reads of the slab 0.7 k -- no single limiter is left.
       static_assert(NSLICE == 7, "the staging schedule of the 256-channel tiles is written for 7 slices");
       for (int c = 0; c < a.nchunk; ++c) {
         const bool last_chunk = c + 1 == a.nchunk;
