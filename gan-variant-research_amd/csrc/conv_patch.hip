@@ -104,6 +104,7 @@ template <int BM, int WGN, int NT, bool FP8 = false, int NS = 7, int BN = 128>
 __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
   static_assert(!FP8 || NT == 0, "the fp8 path uses the generic tap loop");
   static_assert(BN == 128 || (BN == 256 && WGN == 4 && NT == 0 && !FP8), "256-channel tiles: 2 x 4 waves, generic tap loop, bf16");
+  static_assert(NS == 7 || BM == 256, "the 9-slice buffers exist for the 256-row tile only");
   constexpr int NSLICE = NS, PATCHB = NS * 64 * 128;
   constexpr int FI = BM / (8 / WGN) / 16, FJ = BN / WGN / 16;   // fragments per wave: FI pixel groups x FJ channel groups
   extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -389,7 +390,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
       // Where the other 5.8 k cycles of a slab go (each fetch class compiled out in turn, results wrong, timing only): activation
       // re-reads 2.8 k (LDS latency: 8 MFMAs of cover, a second register set does not fit), weight fetches 1.8 k, staging 0.5 k,
       // barrier + first reads of the slab 0.7 k -- no single limiter is left.
-      static_assert(NSLICE == 7, "the staging schedule of the 256-channel tiles is written for 7 slices");
+      constexpr int STAGED_TAPS = (NSLICE + 2) / 2;    // taps whose k-steps carry the NSLICE + 1 staging slots (fetch of slice s, then its LDS write)
       for (int c = 0; c < a.nchunk; ++c) {
         const bool last_chunk = c + 1 == a.nchunk;
         const TileGeo gs = last_chunk ? gn : g;
@@ -446,11 +447,20 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
 #pragma unroll
         for (int i = 0; i < FI; ++i) Xa[i] = *reinterpret_cast<const u32x4_t*>(pb + xaddr[i]);   // Wa: fetched by the previous slab's last k-step (or the prologue)
         using IC = integral_constant<int, -1>;
-        tap(IC{}, integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, 1>{}, 0);
-        tap(integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 2>{}, integral_constant<int, 3>{}, 1);
-        tap(integral_constant<int, 3>{}, integral_constant<int, 4>{}, integral_constant<int, 4>{}, integral_constant<int, 5>{}, 2);
-        tap(integral_constant<int, 5>{}, integral_constant<int, 6>{}, integral_constant<int, 6>{}, IC{}, 3);
-        for (int t = 4; t < a.ntaps; ++t) tap(IC{}, IC{}, IC{}, IC{}, t);
+        // k-step ks (= 2 * tap + half) writes slice ks - 1 and fetches slice ks, while they exist
+        auto staged_tap = [&](auto t_tag) {
+          constexpr int T = decltype(t_tag)::value;
+          constexpr int S0 = 2 * T - 1, L0 = 2 * T, S1 = 2 * T, L1 = 2 * T + 1;
+          tap(integral_constant<int, (S0 >= 0 && S0 < NSLICE) ? S0 : -1>{}, integral_constant<int, L0 < NSLICE ? L0 : -1>{},
+              integral_constant<int, S1 < NSLICE ? S1 : -1>{}, integral_constant<int, L1 < NSLICE ? L1 : -1>{}, T);
+        };
+        staged_tap(integral_constant<int, 0>{});
+        staged_tap(integral_constant<int, 1>{});
+        staged_tap(integral_constant<int, 2>{});
+        staged_tap(integral_constant<int, 3>{});
+        if constexpr (STAGED_TAPS > 4) staged_tap(integral_constant<int, 4>{});
+        static_assert(STAGED_TAPS <= 5, "at most 9 slices");
+        for (int t = STAGED_TAPS; t < a.ntaps; ++t) tap(IC{}, IC{}, IC{}, IC{}, t);
         __syncthreads();
         pcur ^= 1;
         stamp();
@@ -688,7 +698,10 @@ static int patch_span(const gan_conv_desc* d, int BM) {
 // multiple of it and the 256-wide tiles still fill the chip (bf16, >= 4 taps, maps up to 64 pixels wide: the 7-slice buffers), else 128.
 // GAN_PATCH_BN = 128 | 256 forces one wherever the layer is eligible (a tuning / test aid that only the planning call reads).
 static int patch_bn(const gan_conv_desc* d, int BM, bool planning = false) {
-  const bool eligible = d->dtype == GAN_BF16 && d->Nw % 256 == 0 && d->Nst % 256 == 0 && d->ntaps >= 4 && patch_span(d, BM) <= RMAX;
+  // >= 4 taps (5 on maps wider than 64 pixels, whose 9 slices take 10 k-steps): the staging schedule is unrolled over the first taps
+  const int span = patch_span(d, BM);
+  const bool eligible = d->dtype == GAN_BF16 && d->Nw % 256 == 0 && d->Nst % 256 == 0 &&
+                        ((span <= RMAX && d->ntaps >= 4) || (BM == 256 && span <= RMAX_WIDE && d->ntaps >= 5));
   if (!eligible) return 128;
   if (!planning && (d->tile_cols == 128 || d->tile_cols == 256)) return d->tile_cols;
   if (planning) {
@@ -806,7 +819,8 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
     if (!raise((const void*)conv_patch_kernel<256, 2, 0>, lds_bytes(7)) || !raise((const void*)conv_patch_kernel<288, 4, 0>, lds_bytes(7)) ||
         !raise((const void*)conv_patch_kernel<256, 2, 9>, lds_bytes(7)) || !raise((const void*)conv_patch_fp8_kernel, lds_bytes(7)) ||
         !raise((const void*)conv_patch_kernel<256, 2, 0, false, 9>, lds_bytes(9)) || !raise((const void*)conv_patch_fp8_wide_kernel, lds_bytes(9)) ||
-        !raise((const void*)conv_patch_kernel<256, 4, 0, false, 7, 256>, lds_bytes(7)) || !raise((const void*)conv_patch_kernel<288, 4, 0, false, 7, 256>, lds_bytes(7)))
+        !raise((const void*)conv_patch_kernel<256, 4, 0, false, 7, 256>, lds_bytes(7)) || !raise((const void*)conv_patch_kernel<288, 4, 0, false, 7, 256>, lds_bytes(7)) ||
+        !raise((const void*)conv_patch_kernel<256, 4, 0, false, 9, 256>, lds_bytes(9)))
       return gan_set_error(-2, "conv_patch: cannot raise the dynamic LDS limit to %d bytes", lds_bytes(9));
     attr_devs.fetch_or(dev_bit, std::memory_order_release);
   }
@@ -819,7 +833,8 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
     if (wide) hipLaunchKernelGGL(conv_patch_fp8_wide_kernel, dim3(grid), dim3(NTHR), lds_bytes(9), s, a);
     else hipLaunchKernelGGL(conv_patch_fp8_kernel, dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
   } else if (BN == 256) {
-    if (BM == 256) hipLaunchKernelGGL((conv_patch_kernel<256, 4, 0, false, 7, 256>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
+    if (BM == 256 && wide) hipLaunchKernelGGL((conv_patch_kernel<256, 4, 0, false, 9, 256>), dim3(grid), dim3(NTHR), lds_bytes(9), s, a);
+    else if (BM == 256) hipLaunchKernelGGL((conv_patch_kernel<256, 4, 0, false, 7, 256>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<288, 4, 0, false, 7, 256>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
   } else if (BM == 256) {
     if (wide) hipLaunchKernelGGL((conv_patch_kernel<256, 2, 0, false, 9>), dim3(grid), dim3(NTHR), lds_bytes(9), s, a);

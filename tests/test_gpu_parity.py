@@ -31,15 +31,21 @@ def test_conv_geometry_hip_tile288(geom, monkeypatch):
     cases.run_conv_geometry(hip_ctx(BF16), geom, BF16, B=3)
 
 
+WIDE_MAP_256 = (256, 256, 3, 1, 1, False, 128, True)     # a residual layer of a 512x512 image: 9-slice buffers (256-row tile only)
+
+
 @pytest.mark.parametrize("bm", ["256", "288"])
-@pytest.mark.parametrize("geom", [g for g in cases.GEOMS if g[1] % 256 == 0 and g[3] == 1 and not g[5]])
+@pytest.mark.parametrize("geom", [g for g in cases.GEOMS if g[1] % 256 == 0 and g[3] == 1 and not g[5]] + [WIDE_MAP_256])
 def test_conv_geometry_hip_tile_cols256(geom, bm, monkeypatch):
     """The 256-channel tiles of the range-patch kernel (whole Cout of the residual layers per tile; chosen on launches of >= 192 such
-    tiles) at both tile heights: forced here on the small geometries (3x3 256->256 forward / reflect-padded input gradient, 4x4 256->512)."""
+    tiles) at both tile heights: forced here on the small geometries (3x3 256->256 forward / reflect-padded input gradient, 4x4 256->512)
+    and on one 128-pixel-wide map."""
+    if geom == WIDE_MAP_256 and bm == "288":
+        pytest.skip("maps wider than 64 pixels: 256-row tile only")
     monkeypatch.setenv("GAN_PATCH_BN", "256")
     monkeypatch.setenv("GAN_PATCH_BM", bm)
     ctx = hip_ctx(BF16)
-    cases.run_conv_geometry(ctx, geom, BF16, B=3)
+    cases.run_conv_geometry(ctx, geom, BF16, B=3 if geom != WIDE_MAP_256 else 1)
     cin, cout, k = geom[0], geom[1], geom[2]
     from gan_variant_research_amd.runtime import ConvCall  # noqa: F401  (the planner really chose the wide tile)
     from gan_variant_research_amd.convplan import ConvLayer
