@@ -374,8 +374,11 @@ class ConvLayer:
                          max_tapoff=((k - 1) * xo.Wp + (k - 1)) * cx)
         spi = ops.wgrad_patch_splits(call)
         w7 = ops.wgrad_win7_splits(call) if spi == 0 else 0
-        if spi > 0:      # range-patch kernel: splits never cross an image
+        if spi > 0:      # range-patch kernel: spi splits per image
             call.nsplit, call.variant = g.B * spi, 1
+        elif spi < 0:    # ... or, on many small maps, -spi whole images per split
+            assert g.B % -spi == 0
+            call.nsplit, call.variant = g.B // -spi, 1
         elif w7 > 0:     # the 64 -> 3 channel 7x7 layer: one slab per persistent block
             call.nsplit, call.variant = w7, 2
         else:

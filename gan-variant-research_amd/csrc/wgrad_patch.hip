@@ -36,6 +36,7 @@ constexpr int LDS_BYTES_RING = 2 * GT_BYTES + RING_SLOTS * RING_PITCH * 128;
 struct WpArgs {
   const char* x; const char* g; float* part;
   int B, HoWo, Wo, lgWo, spi, per;   // spi: splits per image, per: pixels per split (multiple of KM)
+  int ipb;                           // images per split (> 1: small maps, spi = 1 -- a block accumulates over ipb whole images)
   int Cx, N, pitch, nrows;           // pitch: padded window row pitch (pixels, multiple of 8); nrows: image rows per window
   int x_Hp, x_Wp, x_y0, x_x0;        // x_y0/x_x0: position of tap (0,0) of output pixel (0,0) inside the padded image
   int g_Hp, g_Wp, g_C, g_y0, g_x0;
@@ -57,10 +58,11 @@ __global__ __launch_bounds__(512) void wgrad_patch_kernel(WpArgs a) {
   int bid = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int cb = bid % a.CBLK; bid /= a.CBLK;
   const int nb = bid % a.NBLK; bid /= a.NBLK;
-  const int sp = bid;                                  // split index: image b = sp / spi, sub-range sp % spi
-  const int b = sp / a.spi, sub = sp - b * a.spi;
+  const int sp = bid;                                  // split index: image b0 = sp / spi, sub-range sp % spi -- or ipb whole images from sp * ipb
+  const int b0 = a.ipb > 1 ? sp * a.ipb : sp / a.spi, sub = a.ipb > 1 ? 0 : sp - b0 * a.spi;
   const int m_begin = sub * a.per, m_end = min(a.HoWo, m_begin + a.per);
-  const int nstage = (m_end - m_begin + KM - 1) / KM;
+  const int nst_img = (m_end - m_begin + KM - 1) / KM;   // stages per image
+  const int nstage = nst_img * a.ipb;                    // the stage pipeline runs across the images of the split
   const int n0 = nb * NB, c0 = cb * CB;
 
   // ---- staging roles (LDS-DMA, lane-linear images, XOR applied on the SOURCE chunk)
@@ -74,6 +76,7 @@ __global__ __launch_bounds__(512) void wgrad_patch_kernel(WpArgs a) {
 
   char* const ring = lds + 2 * GT_BYTES;                 // RING: [RING_SLOTS][pitch][128 B] behind the two g tiles
   const uint32_t ring_rowb = (uint32_t)(a.pitch * 128);
+  const int b = b0;                                      // RING variant: one image per split
   auto load_row = [&](int iy) {                          // RING: one padded image row -> its slot
     char* slot = ring + (uint32_t)(iy & (RING_SLOTS - 1)) * ring_rowb;
     const int iyc = iy < a.x_Hp ? iy : a.x_Hp - 1;
@@ -90,7 +93,8 @@ __global__ __launch_bounds__(512) void wgrad_patch_kernel(WpArgs a) {
   auto stage = [&](int st, int buf) {
     char* gt = lds + buf * (RING ? GT_BYTES : STAGE_BYTES);
     char* xw = gt + GT_BYTES;
-    const int m0 = m_begin + st * KM, ho0 = m0 >> a.lgWo;
+    const int img = st / nst_img, b = b0 + img;
+    const int m0 = m_begin + (st - img * nst_img) * KM, ho0 = m0 >> a.lgWo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int m = m0 + gr + 32 * i;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(512) void wgrad_patch_kernel(WpArgs a) {
     __syncthreads();   // stage st landed (LDS-DMA drained + barrier); everyone is done with the other buffer
     char* gt = lds + (st & 1) * (RING ? GT_BYTES : STAGE_BYTES);
     const char* xw = RING ? ring : gt + GT_BYTES;
-    const int m0 = m_begin + st * KM;
+    const int m0 = m_begin + (st % nst_img) * KM;
     uint32_t so[3] = {0u, 0u, 0u};                        // RING: byte offset of the slot of tap row dy
     if constexpr (RING) {
       const int iy0 = (m0 >> a.lgWo) + a.x_y0;
@@ -226,13 +230,18 @@ extern "C" int gan_wgrad_patch_splits(const gan_wgrad_desc* d) {
   if (d->Wo < 16 || (d->Wo & (d->Wo - 1)) != 0 || KM % d->Wo != 0 || d->max_tapoff != (2 * d->x_Wp + 2) * d->Cx) return 0;
   const int HoWo = d->Ho * d->Wo;
   if (HoWo < KM) return 0;
-  // Splits never cross an image, so many small images mean many short splits: each block then runs only a few stages between a
-  // full prologue and a 300 KB partial store, and the reduction reads B slabs (Basic_GAN 16x16 maps at batch 256: 0.77x of the
-  // generic kernel, measured).  Require at least 8 stages per split at the split count this kernel would use.
-  if (HoWo < 8 * KM && d->B > 64) return 0;
   const int pitch = (d->Wo + 2 + 7) / 8 * 8, nrows = KM / d->Wo + 2;
   if (nrows * pitch > RX && !(d->Wo == KM && pitch == RING_PITCH)) return 0;     // 128-wide maps: the row-ring variant
   const int blocks_per_split = (d->N / NB) * (d->Cx / CB);
+  // Many small images (Basic_GAN: 16x16 maps at batch 256): with one split per image a block runs two stages between a full prologue and
+  // a 300 KB partial store, and the reduction reads B slabs (0.77x of the generic kernel, measured).  A split then covers SEVERAL whole
+  // images -- the negative return value: -(images per split), the largest divisor of B that still leaves one block per CU.
+  if (HoWo < 8 * KM && d->B * blocks_per_split > 256 && HoWo % KM == 0 && nrows * pitch <= RX) {
+    int ipb = d->B * blocks_per_split / 256;
+    while (ipb > 1 && d->B % ipb != 0) --ipb;
+    if (ipb > 1) return -ipb;
+  }
+  if (HoWo < 8 * KM && d->B > 64) return 0;
   int spi = (256 + d->B * blocks_per_split - 1) / (d->B * blocks_per_split);   // ~one block per CU
   const int max_spi = HoWo / (2 * KM) > 0 ? HoWo / (2 * KM) : 1;
   if (spi > max_spi) spi = max_spi;
@@ -242,10 +251,13 @@ extern "C" int gan_wgrad_patch_splits(const gan_wgrad_desc* d) {
 
 int gan_wgrad_patch_launch(const gan_wgrad_desc* d, hipStream_t s) {
   const int spi_want = gan_wgrad_patch_splits(d);
-  GAN_CHECK(spi_want > 0 && d->nsplit % d->B == 0, "wgrad: variant=1 but the descriptor does not qualify for the range-patch kernel");
+  GAN_CHECK(spi_want != 0 && d->nsplit > 0 && (d->nsplit % d->B == 0 || (d->B % d->nsplit == 0 && (d->Ho * d->Wo) % KM == 0)),
+            "wgrad: variant=1 but the descriptor does not qualify for the range-patch kernel");
   WpArgs a;
   a.x = (const char*)d->x; a.g = (const char*)d->g; a.part = d->part;
-  a.B = d->B; a.HoWo = d->Ho * d->Wo; a.Wo = d->Wo; a.lgWo = __builtin_ctz(d->Wo); a.spi = d->nsplit / d->B;
+  a.B = d->B; a.HoWo = d->Ho * d->Wo; a.Wo = d->Wo; a.lgWo = __builtin_ctz(d->Wo);
+  a.ipb = d->nsplit < d->B ? d->B / d->nsplit : 1;      // fewer splits than images: whole images per split
+  a.spi = a.ipb > 1 ? 1 : d->nsplit / d->B;
   int per = (a.HoWo + a.spi - 1) / a.spi;
   per = (per + KM - 1) / KM * KM;
   a.per = per;

@@ -97,7 +97,7 @@ typedef struct gan_wgrad_desc {
   int32_t g_Hp, g_Wp, g_C, g_y0, g_x0, g_sy, g_sx;
   float* part;                   /* device fp32 [nsplit][N][ntaps][Cx] */
   int32_t max_tapoff;            /* largest value in tapoff[] (range-patch variant's span check) */
-  int32_t variant;               /* 0: generic kernel, any nsplit; 1: range-patch kernel, nsplit = B * gan_wgrad_patch_splits();
+  int32_t variant;               /* 0: generic kernel, any nsplit; 1: range-patch kernel, nsplit = B * gan_wgrad_patch_splits() (or B / -that);
                                     2: 7x7 window kernel, nsplit = gan_wgrad_win7_splits() */
 } gan_wgrad_desc;
 
@@ -127,7 +127,8 @@ int gan_conv_win7_ok(const gan_conv_desc* d);
 int gan_conv_stats_parts(const gan_conv_desc* d);
 int gan_conv_wgrad(const gan_wgrad_desc* d, void* stream);
 /* splits per image the range-patch weight-gradient kernel wants (0: the descriptor does not qualify: bf16, 9 taps, stride 1,
- * Cx % 64 == 0, N % 128 == 0, one 128-pixel stage's window span fits LDS); pure host-side predicate for the planner */
+ * Cx % 64 == 0, N % 128 == 0, one 128-pixel stage's window span fits LDS); pure host-side predicate for the planner.
+ * A NEGATIVE value -k means k whole images per split (many small maps, e.g. 16x16 at batch 256): nsplit = B / k. */
 int gan_wgrad_patch_splits(const gan_wgrad_desc* d);
 /* grad[(a*I2 + b)*KK + khw[t]] (+)= sum_s part[s][n][t][c], (a,b) = swap ? (c,n) : (n,c), for n<N_real, c<C_real, khw[t]>=0 */
 /* slabs the 7x7 window weight-gradient kernels write (0: the descriptor does not qualify: bf16, 49 row-major taps, stride 1, and

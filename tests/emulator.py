@@ -236,13 +236,20 @@ class EmuOps:
             return 0
         if (c.x_sy, c.x_sx, c.g_sy, c.g_sx) != (1, 1, 1, 1) or c.Ho * c.Wo < 128:
             return 0
-        if c.Ho * c.Wo < 8 * 128 and c.B > 64:      # many small images: short splits, B slabs to reduce
-            return 0
         if c.Wo < 16 or c.Wo & (c.Wo - 1) or 128 % c.Wo or c.max_tapoff != (2 * c.x.Wp + 2) * c.Cx:
             return 0
-        if (128 // c.Wo + 2) * ((c.Wo + 2 + 7) // 8 * 8) > 320 and c.Wo != 128:      # 128-wide maps: the row-ring variant
+        window = (128 // c.Wo + 2) * ((c.Wo + 2 + 7) // 8 * 8)
+        if window > 320 and c.Wo != 128:      # 128-wide maps: the row-ring variant
             return 0
         bps = (c.N // 128) * (c.Cx // 64)
+        if c.Ho * c.Wo < 8 * 128 and c.B * bps > 256 and (c.Ho * c.Wo) % 128 == 0 and window <= 320:
+            ipb = c.B * bps // 256        # many small images: a split covers -return whole images
+            while ipb > 1 and c.B % ipb:
+                ipb -= 1
+            if ipb > 1:
+                return -ipb
+        if c.Ho * c.Wo < 8 * 128 and c.B > 64:      # many small images, no even grouping: short splits, B slabs to reduce
+            return 0
         spi = (256 + c.B * bps - 1) // (c.B * bps)
         return max(1, min(spi, max(1, c.Ho * c.Wo // 256)))
 

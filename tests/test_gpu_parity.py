@@ -58,6 +58,20 @@ def test_conv_geometry_hip_tile_cols256(geom, bm, monkeypatch):
     assert layer.last_call.tile_cols == 256 and layer.last_call.tile_rows == int(bm)
 
 
+def test_wgrad_patch_splits_spanning_images():
+    """Many small maps (Basic_GAN's residual layers: 16x16 at batch 256): the range-patch weight gradient lets one split accumulate over
+    several whole images (gan_wgrad_patch_splits < 0).  Batch 64 is the smallest that triggers it for 256 -> 256 channels (2 images per split)."""
+    from gan_variant_research_amd.convplan import ConvLayer
+    geom = (256, 256, 3, 1, 1, False, 16, True)
+    ctx = hip_ctx(BF16)
+    cases.run_conv_geometry(ctx, geom, BF16, B=64)
+    w = torch.zeros(256, 256, 3, 3, device=DEV)
+    layer = ConvLayer(ctx, w, torch.zeros(256, device=DEV), torch.zeros_like(w), torch.zeros(256, device=DEV), 3, 1, 1, False)
+    x, dy = ctx.view(64, 16, 16, 256, 1), ctx.view(64, 16, 16, 256, 2)
+    call = layer.wgrad(x, dy, False, bias_too=False)[0].wgrad
+    assert call.variant == 1 and call.nsplit == 32, (call.variant, call.nsplit)
+
+
 @pytest.mark.parametrize("geom", [g for g in cases.GEOMS if g[2] == 7 and max(g[0], g[1]) == 64])
 def test_conv_7x7_window_kernel_is_taken(geom):
     """The 64 <-> 3 channel 7x7 layers run on the two window kernels in bf16 (64->3: output conv forward, first conv's input gradient;
