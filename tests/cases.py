@@ -130,8 +130,8 @@ def small_config():
 
 
 
-def run_cut_steps(device, ops, use_aug, amp=False, S=32, B=2, nsteps=2, tol0=2e-4, tol1=2e-3, atol1=2e-4, ptol=4.5e-4, fp8=False):
-    torch.set_num_threads(4)
+def run_cut_steps(device, ops, use_aug, amp=False, S=32, B=2, nsteps=2, tol0=2e-4, tol1=2e-3, atol1=2e-4, ptol=4.5e-4, fp8=False, threads=4):
+    torch.set_num_threads(threads)
     cfg = small_config()
     cfg["diffaugment"]["enable"] = use_aug
     C.set_seed(42)

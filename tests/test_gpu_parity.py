@@ -336,6 +336,22 @@ def test_cut_train_step_fp32_vs_oracle(use_aug):
     np.testing.assert_allclose(img.numpy(), ref_img.numpy(), rtol=1e-3, atol=1e-3)
 
 
+def test_cut_train_step_fp32_vs_oracle_at_benchmark_resolution():
+    """The same comparison at 256x256 (the benchmark's image size; batch 2, one step, DiffAugment on): the kernels the bench runs -- 64x64
+    residual maps, 66x66 input-gradient domains, the 7x7 window kernels on 256x256 maps -- against the PyTorch-CPU oracle within 1e-3."""
+    torch.set_num_threads(16)
+    tr, img, ref_img = cases.run_cut_steps(DEV, HipOps(torch.device(DEV)), True, amp=False, S=256, B=2, nsteps=1, tol0=1e-3, ptol=4.5e-4, threads=16)
+    np.testing.assert_allclose(img.numpy(), ref_img.numpy(), rtol=1e-3, atol=1e-3)
+
+
+def test_cut_train_step_bf16_vs_oracle_at_benchmark_resolution(monkeypatch):
+    """The benched mode (bf16 operands, fp32 accumulation) at 256x256 with the planner's large-batch choices forced (256-channel
+    range-patch tiles), against the oracle with the bf16 tolerance (8-bit mantissa: 4e-2 on the losses, 5e-2 absolute on the image)."""
+    monkeypatch.setenv("GAN_PATCH_BN", "256")
+    tr, img, ref_img = cases.run_cut_steps(DEV, HipOps(torch.device(DEV)), True, amp=True, S=256, B=2, nsteps=1, tol0=4e-2, ptol=4.5e-4, threads=16)
+    assert float((img - ref_img).abs().max()) < 5e-2
+
+
 def test_cut_train_step_bf16_vs_oracle():
     """bf16 throughput mode (fp32 accumulation): same step, tolerance widened to bf16's 8-bit mantissa."""
     tr, img, ref_img = cases.run_cut_steps(DEV, HipOps(torch.device(DEV)), True, amp=True, S=64, B=2, nsteps=1, tol0=4e-2, ptol=4.5e-4)
