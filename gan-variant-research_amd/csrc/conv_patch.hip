@@ -34,6 +34,7 @@ struct PatchArgs {
   int B, M_img, Wo, MT_img, NTILES, tiles;
   uint32_t wo_magic;            // ceil(2^32 / Wo): m / Wo == umulhi(m, wo_magic) for every output pixel index m of one image (host-checked)
   int Cin, nchunk, ntaps, KB;                             // KB = Ktot/32 fragment blocks per 16-row weight tile
+  int nslice;                                             // 64-pixel slices of the patch buffer a tile really spans (<= NS)
   int in_Hp, in_Wp, in_y0, in_x0, in_sy, in_sx, in_pix;   // in_pix: pixels in the whole input tensor
   int out_Hp, out_Wp, out_C, out_y0, out_x0, out_sy, out_sx;
   int Nst, act;
@@ -173,7 +174,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
   {
     u32x4_t tmp[NSLICE];
 #pragma unroll
-    for (int j = 0; j < NSLICE; ++j) tmp[j] = slab_load(g, 0, j);
+    for (int j = 0; j < NSLICE; ++j) tmp[j] = slab_load(g, 0, j < a.nslice ? j : 0);     // slices past the tile's span: a harmless re-read
 #pragma unroll
     for (int j = 0; j < NSLICE; ++j) slab_store(0, j, tmp[j]);
   }
@@ -472,8 +473,25 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
       const TileGeo gs = last_chunk ? gn : g;   // owner of the next slab
       const int cs = last_chunk ? 0 : c + 1;
       const char* pb = pbuf + pcur * PATCHB;
-      u32x4_t stg = {0, 0, 0, 0};
-      int sj = 0;          // next slice to fetch; slice sj-1 is in `stg` waiting to be written
+      // Staging of the next slab: two slots per tap (one behind each weight fetch); a slot fetches `sps` slices (1, 2 or 4: few-tap
+      // layers -- the sub-pixel phases of the transposed convolutions have 1, 2 or 4 taps -- would otherwise leave most of the slab to
+      // a serial flush after the taps: measured 5 exposed fetch -> write round trips per slab on a 2-tap layer) and writes the slices
+      // the previous slot fetched; only the a.nslice slices the tile's span touches are moved
+      u32x4_t stg[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+      const int nsl = a.nslice;
+      const int sps = 2 * a.ntaps - 1 >= nsl ? 1 : (2 * (2 * a.ntaps - 1) >= nsl ? 2 : 4);
+      int slot = 0;
+      auto stage_slot = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (u < sps) {
+            const int sl_prev = (slot - 1) * sps + u, sl = slot * sps + u;
+            if (slot > 0 && sl_prev < nsl) slab_store(pcur ^ 1, sl_prev, stg[u]);
+            if (sl < nsl) stg[u] = slab_load(gs, cs, sl);
+          }
+        }
+        ++slot;
+      };
 
       // A fragments of one k-step of tap t: 4 x ds_read_b128 from the slab at the tap's row shift.  The second k-step's
       // chunk index differs by 4, i.e. its swizzled address is the first one's XOR 64.
@@ -506,11 +524,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
         w_load(g.n0, kb_cur + 1, Wb);
         x_load(1, Xb);
         const int toff_next = taptab[last_tap ? t : t + 1];   // fetched a half step before x_addr needs it
-        if (stage_next) {
-          if (sj > 0 && sj <= NSLICE) slab_store(pcur ^ 1, sj - 1, stg);
-          if (sj < NSLICE) stg = slab_load(gs, cs, sj);
-          ++sj;
-        }
+        if (stage_next) stage_slot();
         __builtin_amdgcn_sched_barrier(0);
         mma_part(Wa, Xa, FI / 4, FI);
         __builtin_amdgcn_sched_barrier(0);
@@ -518,16 +532,13 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
         __builtin_amdgcn_sched_barrier(0);
         w_load(nn0, kb_next, Wa);
         if (!last_tap) { x_addr(toff_next); x_load(0, Xa); }   // the next slab's activations wait for the barrier
+        if (stage_next) stage_slot();
         __builtin_amdgcn_sched_barrier(0);
         mma_part(Wb, Xb, FI / 4, FI);
       }
-      // flush the slices the taps did not get to (few-tap layers), then hand the buffer over
+      // write what the last slot fetched (and, on one-tap layers, fetch and write the rest), then hand the buffer over
       if (stage_next) {
-        while (sj <= NSLICE) {
-          if (sj > 0) slab_store(pcur ^ 1, sj - 1, stg);
-          if (sj < NSLICE) stg = slab_load(gs, cs, sj);
-          ++sj;
-        }
+        while ((slot - 1) * sps < nsl) stage_slot();
       }
       __syncthreads();   // every wave is done with slab `pcur`; slab `pcur^1` is completely written
       pcur ^= 1;
@@ -795,6 +806,7 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   a.Cin = fp8 ? d->Cin / 2 : d->Cin;          // 2-byte slots per pixel and tap
   a.tapdiv = d->Cin; a.w_scale = d->w_scale; a.in_scale = d->in_scale;
   a.nchunk = a.Cin / 64; a.ntaps = d->ntaps; a.KB = d->ntaps * a.Cin / 32;
+  a.nslice = (patch_span(d, BM) + 63) / 64;
   a.w_bytes = d->Nw * d->ntaps * a.Cin * 2;
   a.out_bytes = (uint32_t)((int64_t)d->B * d->out_Hp * d->out_Wp * d->out_C * 2);
   a.mask_bytes = d->mask ? (uint32_t)((int64_t)d->B * d->mask_Hp * d->mask_Wp * d->out_C * 2) : 0;
