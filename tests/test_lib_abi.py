@@ -68,3 +68,37 @@ def test_library_shares_the_hip_runtime_torch_uses():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_planner_predicates_equal_their_emulator_statements():
+    """gan_conv_patch_ok / gan_conv_stats_parts-free planning and gan_wgrad_patch_splits are pure host functions: the library's answers
+    must equal the statements in tests/emulator.py (which is what the CPU suite plans with) on the shapes the trainers meet -- CUT's
+    64x64 residual maps, Basic_GAN's 16x16 ones at batch 256 (splits spanning several whole images: negative answer), 128-wide maps."""
+    import torch
+    from gan_variant_research_amd import BF16
+    from gan_variant_research_amd.convplan import ConvLayer
+    from gan_variant_research_amd.runtime import Ctx, HipOps
+    from tests.emulator import EmuOps
+    emu, hip = EmuOps(), HipOps(torch.device("cpu"))          # no launch is built or run on `hip`: descriptors only
+    convs, wgrads = [], []
+    conv_op, wgrad_op = emu.conv_igemm, emu.conv_wgrad
+    emu.conv_igemm = lambda c: (convs.append(c), conv_op(c))[1]
+    emu.conv_wgrad = lambda c: (wgrads.append(c), wgrad_op(c))[1]
+    ctx = Ctx(emu, torch.device("cpu"), BF16)
+    seen_negative = False
+    for B, H, Cc in ((2, 64, 256), (16, 64, 256), (64, 16, 256), (256, 16, 256), (48, 16, 256), (8, 128, 128), (16, 32, 256), (3, 20, 64)):
+        w = torch.zeros(Cc, Cc, 3, 3)
+        layer = ConvLayer(ctx, w, torch.zeros(Cc), torch.zeros_like(w), torch.zeros(Cc), 3, 1, 1)
+        x, y = ctx.view(B, H, H, Cc, 1), ctx.view(B, H, H, Cc, 0)
+        dy, dx = ctx.view(B, H, H, Cc, 2), ctx.view(B, H, H, Cc, 1)
+        del convs[:], wgrads[:]
+        layer.fwd(x, y)
+        layer.dgrad(dy, dx, padded_domain=True)
+        layer.wgrad(x, dy, False, bias_too=False)
+        assert len(convs) == 2 and len(wgrads) == 1
+        for c in convs:
+            assert bool(hip.conv_patch_ok(c)) == bool(emu.conv_patch_ok(c)), (B, H, Cc, c.Ho)
+        a, b = hip.wgrad_patch_splits(wgrads[0]), emu.wgrad_patch_splits(wgrads[0])
+        assert a == b, (B, H, Cc, a, b)
+        seen_negative = seen_negative or a < 0
+    assert seen_negative
