@@ -1,6 +1,6 @@
-"""Forward / input gradient / weight gradient of one 3x3 256->256 residual-layer convolution at any (B, H): python tools/probe/res_layer.py B H"""
+"""Forward / input gradient / weight gradient of one 3x3 256->256 residual-layer convolution at any (B, H): python tools/bench_res_layer.py B H"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gan_variant_research_amd import BF16
 from gan_variant_research_amd.convplan import ConvLayer
 from gan_variant_research_amd.runtime import Ctx, HipOps
