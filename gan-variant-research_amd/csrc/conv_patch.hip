@@ -390,7 +390,8 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
       // 288 rows 27.3 k = 76 % (the 128-channel tiles: 69-73 %) and half the epilogues; forward 65.6 -> 58.4 us, input gradient 75.7 -> 64.5 us.
       // Where the other 5.8 k cycles of a slab go (each fetch class compiled out in turn, results wrong, timing only): activation
       // re-reads 2.8 k (LDS latency: 8 MFMAs of cover, a second register set does not fit), weight fetches 1.8 k, staging 0.5 k,
-      // barrier + first reads of the slab 0.7 k -- no single limiter is left.
+      // barrier + first reads of the slab 0.7 k -- no single limiter is left.  (A second activation set for the 256-row tile, filled during the
+      // first channel fragment of the previous k-step -- 24 MFMAs of cover -- measured SLOWER: 24.1 k -> 25.0 k cycles per slab.)
       constexpr int STAGED_TAPS = (NSLICE + 2) / 2;    // taps whose k-steps carry the NSLICE + 1 staging slots (fetch of slice s, then its LDS write)
       for (int c = 0; c < a.nchunk; ++c) {
         const bool last_chunk = c + 1 == a.nchunk;
