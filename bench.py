@@ -27,7 +27,10 @@ if ROOT not in sys.path:
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 PEAK_FP8_TFLOPS = 5000.0    # dense fp8 MFMA peak (v_mfma_scale_f32_16x16x128_f8f6f4), same guide
-GFLOP_PER_IMAGE = 935.9     # canonical algorithmic conv FLOPs of one step per image at 256^2 (identity on)
+# canonical algorithmic conv FLOPs of one step per image at 256^2 (identity on) = 935.9 GFLOP, MINUS what this build does not
+# execute: the reference's get_feature_layers also runs the second up-sampling layer, whose output no PatchNCE layer id reaches (ids stop
+# at 12); the feature pass here stops behind id 12.  ConvT 128->64 on 128x128: 2.416 GFLOP forward, x3 with both gradients.
+GFLOP_PER_IMAGE = 935.9 - 3 * 2.416
 
 
 def default_config():
