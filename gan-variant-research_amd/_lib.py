@@ -74,6 +74,7 @@ PROTOTYPES = {
     "gan_conv_patch_ok": (C.c_int, [PC]),
     "gan_conv_patch_tile_rows": (C.c_int, [PC]),
     "gan_conv_patch_tile_cols": (C.c_int, [PC]),
+    "gan_conv_patch_variant": (C.c_int, [PC]),
     "gan_conv_stats_parts": (C.c_int, [PC]),
     "gan_in_stats_from_parts": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp]),
     "gan_pack_weight": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),

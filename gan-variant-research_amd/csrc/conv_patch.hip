@@ -732,8 +732,8 @@ static int patch_tile_rows(const gan_conv_desc* d, bool planning = false) {
   const int M_img = d->Ho * d->Wo, ncu = 256;
   int BM = 0, forced = 0;
   int64_t best = 0;
+  if (d->dtype == GAN_FP8) return 256;      // only 256-row e4m3 kernels exist: a descriptor's tile_rows cannot ask for another
   if (!planning && (d->tile_rows == 256 || d->tile_rows == 288) && patch_span(d, d->tile_rows) <= (d->tile_rows == 256 ? RMAX_WIDE : RMAX)) return d->tile_rows;
-  if (d->dtype == GAN_FP8) return 256;
   if (planning) { const char* e = getenv("GAN_PATCH_BM"); forced = e ? atoi(e) : 0; }
   for (int cand : {256, 288}) {
     const int lim = cand == 256 ? RMAX_WIDE : RMAX;      // the 9-slice buffers exist for the 256-row tile only
@@ -790,13 +790,27 @@ extern "C" int gan_conv_stats_parts(const gan_conv_desc* d) {
   return (d->Ho * d->Wo + BM - 1) / BM;
 }
 
+// Which instantiation a qualifying descriptor runs on (the launch and the planner's query share this decision):
+// tile rows | tile columns << 12 | LDS slices (7: maps up to 64 pixels wide, 9: up to 128) << 24 | e4m3 operands << 28 | static 3x3 schedule << 29
+static int patch_variant(const gan_conv_desc* d) {
+  static const bool static_off = [] { const char* e = getenv("GAN_PATCH_STATIC"); return e && !atoi(e); }();
+  const int BM = patch_tile_rows(d);
+  const int BN = patch_bn(d, BM);
+  const bool fp8 = d->dtype == GAN_FP8;
+  const int slots = fp8 ? d->Cin / 2 : d->Cin;
+  const bool wide = BM == 256 && patch_span(d, 256) > RMAX;      // needs the 9-slice buffers (maps wider than 64 pixels)
+  const bool st9 = !fp8 && BN == 128 && BM == 256 && !wide && d->ntaps == 9 && (slots / 64) % 2 == 0 && !static_off;
+  return BM | (BN << 12) | ((wide ? 9 : 7) << 24) | ((fp8 ? 1 : 0) << 28) | ((st9 ? 1 : 0) << 29);
+}
+extern "C" int gan_conv_patch_variant(const gan_conv_desc* d) { return gan_conv_patch_ok(d) ? patch_variant(d) : 0; }
+
 int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   if (!gan_conv_patch_ok(d)) return gan_set_error(-1, "conv: w_layout=1 (fragment-major weights) but the descriptor does not qualify for the range-patch kernel");
   PatchArgs a;
   const int M_img = d->Ho * d->Wo;
   const int ncu = 256;
-  const int BM = patch_tile_rows(d);
-  const int BN = patch_bn(d, BM);
+  const int variant = patch_variant(d);
+  const int BM = variant & 0xfff, BN = (variant >> 12) & 0xfff;
   a.in = (const char*)d->in; a.w = (const char*)d->w; a.bias = d->bias; a.out = (char*)d->out; a.mask = (const char*)d->mask; a.tapoff = d->tapoff;
   // m / Wo by multiplication: with magic = ceil(2^32 / Wo) the quotient is exact while m * (magic * Wo - 2^32) < 2^32, i.e. for m * Wo < 2^32
   if ((int64_t)(M_img + 288) * d->Wo >= (1ll << 32) || d->Wo < 1) return gan_set_error(-1, "conv_patch: map too large for the index arithmetic");
@@ -819,7 +833,6 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   a.mask_Hp = d->mask_Hp; a.mask_Wp = d->mask_Wp; a.mask_y0 = d->mask_y0; a.mask_x0 = d->mask_x0;
   // diagnostic environment (stamp buffer, static-schedule switch): read once per process, not per launch
   static unsigned long long* const stamps_env = [] { const char* e = getenv("GAN_PATCH_STAMPS"); return e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }();
-  static const bool static_off = [] { const char* e = getenv("GAN_PATCH_STATIC"); return e && !atoi(e); }();
   a.stamps = stamps_env;
   const int grid = a.tiles < ncu ? a.tiles : ncu;
   // the dynamic-LDS limit is a per-device function attribute: one bit per device, set on that device's first launch
@@ -840,8 +853,7 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   // The static 3x3 schedule, 256-row tile only.  Measured (s_memtime): 15.5 k -> 13.0 k cycles per slab, but the denser issue
   // stream clocks lower (2.04 -> 1.88 GHz), so the forward gains 3 % wall (69.5 -> 67.2 us = 1.15 PFLOP/s); on the 288-row tile,
   // whose 9 fragment addresses per tap do not fit in registers, it lost 9 % and is not instantiated.
-  const bool wide = BM == 256 && patch_span(d, 256) > RMAX;      // needs the 9-slice buffers (maps wider than 64 pixels)
-  const bool st9 = BM == 256 && !wide && d->ntaps == 9 && a.nchunk % 2 == 0 && !static_off;
+  const bool wide = ((variant >> 24) & 0xf) == 9, st9 = (variant >> 29) & 1;
   if (fp8) {
     if (wide) hipLaunchKernelGGL(conv_patch_fp8_wide_kernel, dim3(grid), dim3(NTHR), lds_bytes(9), s, a);
     else hipLaunchKernelGGL(conv_patch_fp8_kernel, dim3(grid), dim3(NTHR), lds_bytes(7), s, a);

@@ -209,7 +209,7 @@ def run_basic_iterations(device, ops, amp=False, S=32, B=2, niter=2, tol0=2e-4, 
     return tr
 
 
-def run_conv_fp8(ctx, B=2, C_=256, H=16, seed=0):
+def run_conv_fp8(ctx, B=2, C_=256, H=16, seed=0, with_stats=False, info=None):
     """The fp8 (e4m3) operand path of the bottleneck 3x3 256->256 convolution (BASELINE.json configs[4]): forward and input gradient
     through gan_quantize_fp8 + gan_pack_weight_batch(FP8) + gan_conv_igemm(dtype FP8) against
       (a) F.conv2d on the SAME e4m3-rounded operands (what the kernel must compute exactly, up to fp32 summation order and the bf16
@@ -227,7 +227,9 @@ def run_conv_fp8(ctx, B=2, C_=256, H=16, seed=0):
     xv = to_view(ctx, x, 1, HALO_REFLECT)
     x8 = ctx.view(B, H, H, C_, 1, dtype=FP8)
     y = ctx.view(B, H, H, C_, 0)
-    ops_f = [ctx.ops.quantize_fp8(xv, x8)] + layer.fwd8(x8, y)
+    stats_ws = ctx.f32(B * 96 * C_ * 2) if with_stats else None
+    ops_f = [ctx.ops.quantize_fp8(xv, x8)] + layer.fwd8(x8, y, stats_ws=stats_ws)
+    calls = {"fwd": getattr(ops_f[-1], "conv", None)}
     # input gradient: dY with a per-image scale, zero halo 2, padded-domain result folded by the consumer
     dy = torch.randn(B, C_, H, H, generator=g) * torch.tensor([1e-3, 3e-5])[:B].view(B, 1, 1, 1)
     dy = dy.bfloat16().float()
@@ -237,11 +239,15 @@ def run_conv_fp8(ctx, B=2, C_=256, H=16, seed=0):
     scale = torch.zeros(B, device=dev)
     dxp = ctx.view(B, H, H, C_, 1)
     dxf = ctx.view(B, H, H, C_, 0)
-    ops_b = [ctx.ops.quantize_fp8(dyv, dy8, amax, scale)] + layer.dgrad8(dy8, dxp, scale, padded_domain=True) + [ctx.ops.fold_add(None, dxp, True, dxf)]
+    ops_d = layer.dgrad8(dy8, dxp, scale, padded_domain=True)
+    calls["dgrad"] = getattr(ops_d[-1], "conv", None)
+    ops_b = [ctx.ops.quantize_fp8(dyv, dy8, amax, scale)] + ops_d + [ctx.ops.fold_add(None, dxp, True, dxf)]
     for o in [ctx.ops.pack_weight_batch([op.pack_args for op in layer.repack_ops()])] + ops_f + ops_b:
         o()
     if ctx.device.type == "cuda":
         torch.cuda.synchronize()
+    if info is not None:
+        info.update(calls)
     sw = float(w.abs().max()) / 448.0
     w8 = _e4m3(w / sw) * sw
     xp = F.pad(x, (1, 1, 1, 1), mode="reflect")
@@ -252,6 +258,15 @@ def run_conv_fp8(ctx, B=2, C_=256, H=16, seed=0):
     assert float((got - exact).abs().max()) < 1e-2 * rms * 4, (float((got - exact).abs().max()), rms)
     assert float((got - full).abs().max()) < 0.12 * rms * 2.5 and float((got - full).pow(2).mean().sqrt()) < 0.05 * rms
     np.testing.assert_allclose(scale.cpu().numpy(), (amax.cpu() / 448.0).numpy(), rtol=1e-6)
+    if with_stats:      # the fused InstanceNorm partials of the e4m3 forward: statistics of the (unrounded) result
+        assert layer.stats_parts > 0
+        st = ctx.f32(B * C_ * 2)
+        ctx.ops.in_stats_from_parts(stats_ws, layer.stats_parts, B, C_, H * H, 1e-5, st)()
+        if ctx.device.type == "cuda":
+            torch.cuda.synchronize()
+        sg = st.cpu().view(B, C_, 2)
+        np.testing.assert_allclose(sg[..., 0].numpy(), exact.mean((2, 3)).numpy(), rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(sg[..., 1].numpy(), (1.0 / torch.sqrt(exact.var((2, 3), unbiased=False) + 1e-5)).numpy(), rtol=2e-3)
     # reference input gradient through autograd on the reflect-padded convolution
     xr = x.clone().requires_grad_(True)
     F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), w, None).backward(dy)

@@ -527,6 +527,35 @@ def test_fp8_conv_path_hip(H):
         assert float((gotd[bi] - emud[bi]).abs().max()) < 2e-2 * float(rmsd[bi])
 
 
+def test_fp8_conv_path_wide_maps_hip():
+    """The kernel `bench.py --fp8 --size 512` runs: at 512x512 the residual maps are 128 pixels wide, a 256-pixel tile spans 522 padded
+    pixels and the launch goes to the 9-slice e4m3 instantiation (conv_patch_fp8_wide_kernel).  Forward (with the fused InstanceNorm
+    partials) and padded-domain input gradient with a per-image scale, same assertions as the narrow case; the planner's choice is
+    asserted through gan_conv_patch_variant."""
+    ctx, info = hip_ctx(BF16), {}
+    got, gotd = cases.run_conv_fp8(ctx, B=1, H=128, with_stats=True, info=info)
+    for which in ("fwd", "dgrad"):
+        v = ctx.ops.conv_patch_variant(info[which])
+        assert v == {"rows": 256, "cols": 128, "slices": 9, "fp8": True, "static9": False}, (which, v)
+    emu, emud = cases.run_conv_fp8(Ctx(EmuOps(), "cpu", BF16), B=1, H=128)
+    rms, rmsd = float(emu.pow(2).mean().sqrt()), emud.pow(2).mean((1, 2, 3)).sqrt()
+    # 4.2 M outputs: some sit on a bf16 rounding boundary, where the two fp32 summation orders land one output ulp (<= 2^-7 |v|) apart
+    assert bool(((got - emu).abs() <= 2e-2 * rms + 2.0 ** -7 * emu.abs()).all()), float((got - emu).abs().max())
+    assert bool(((gotd[0] - emud[0]).abs() <= 2e-2 * float(rmsd[0]) + 2.0 ** -7 * emud[0].abs()).all()), float((gotd[0] - emud[0]).abs().max())
+
+
+def test_cut_train_step_fp8_at_512_vs_oracle():
+    """BASELINE.json configs[4] at its own resolution: one fp8 CUT step at 512x512 (batch 1), where every residual convolution and input
+    gradient runs on the 9-slice e4m3 kernel (asserted), against the fp32 oracle with the tolerances of the 64x64 fp8 step test."""
+    ops = HipOps(torch.device(DEV))
+    seen = []
+    orig = ops.conv_igemm
+    ops.conv_igemm = lambda c: (seen.append(ops.conv_patch_variant(c)) if c.x.dtype == 2 else None, orig(c))[1]
+    tr, img, ref_img = cases.run_cut_steps(DEV, ops, True, amp=True, S=512, B=1, nsteps=1, tol0=8e-2, ptol=4.5e-4, fp8=True, threads=16)
+    assert tr.fp8 and len(seen) >= 36 and all(v.get("fp8") and v.get("slices") == 9 for v in seen), seen[:3]
+    assert float((img - ref_img).abs().max()) < 0.3 and float((img - ref_img).pow(2).mean().sqrt()) < 0.06
+
+
 def test_cut_train_step_fp8_vs_oracle():
     """BASELINE.json configs[4] at test size: the CUT step with e4m3 operand copies for the residual convolutions (forward and input
     gradient) at 64x64 against the fp32 oracle.  Stated fp8 tolerance: step-0 losses within 8 %, generated image within 0.3 max / 0.06 rms."""
