@@ -29,7 +29,8 @@ class GanConvDesc(C.Structure):
                 ("tapoff", vp), ("w", vp), ("bias", vp), ("out", vp),
                 ("out_Hp", i32), ("out_Wp", i32), ("out_C", i32), ("out_y0", i32), ("out_x0", i32), ("out_sy", i32), ("out_sx", i32),
                 ("act", i32), ("mask", vp), ("mask_Hp", i32), ("mask_Wp", i32), ("mask_y0", i32), ("mask_x0", i32), ("stats", vp), ("max_tapoff", i32), ("w_layout", i32),
-                ("win_ty0", i32), ("win_tx0", i32), ("tile_rows", i32), ("tile_cols", i32), ("w_scale", vp), ("in_scale", vp)]
+                ("win_ty0", i32), ("win_tx0", i32), ("tile_rows", i32), ("tile_cols", i32), ("w_scale", vp), ("in_scale", vp),
+                ("stats_mode", i32), ("_pad2", i32)]
 
 
 class GanWgradDesc(C.Structure):
@@ -102,6 +103,7 @@ PROTOTYPES = {
     "gan_in_bwd_bias_parts": (C.c_int, [PV]),
     "gan_in_bwd_bias_deferred": (C.c_int, [PV, vp, C.c_int, PV, C.c_int, PV, PV, vp, vp, vp]),
     "gan_bias_finalize_batch": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+    "gan_in_bwd_parts": (C.c_int, [PV, vp, C.c_int, PV, C.c_int, PV, vp, C.c_int, C.c_int, vp, vp]),
     "gan_resize_ksize": (C.c_int, [C.c_int, C.c_int]),
     "gan_resize_coeffs": (C.c_int, [C.c_int, C.c_int, vp, vp, C.c_int]),
     "gan_input_pipeline": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]),

@@ -313,10 +313,15 @@ class ConvLayer:
         return out
 
     # ------------------------------------------------------------------ input gradient
-    def dgrad(self, dy: View, dx: View, mask: Optional[View] = None, padded_domain: bool = False):
-        """dx <- dL/d(input).  padded_domain: also produce the gradient on the input's (reflect) halo; the consumer folds it."""
+    def dgrad(self, dy: View, dx: View, mask: Optional[View] = None, padded_domain: bool = False, chain: Optional[dict] = None):
+        """dx <- dL/d(input).  padded_domain: also produce the gradient on the input's (reflect) halo; the consumer folds it.
+        chain (stride-1 layers on the padded domain, bf16) = {"operand": y, "ws": parts}: the launch's epilogue also leaves the two sums of
+        the InstanceNorm backward behind a ReLU whose saved output is y (reflect halo p) -- gan_conv_desc.stats_mode 1; self.chain_parts =
+        partials per image written to ws.  Raises GanError if the launch cannot carry it (ask can_chain first)."""
         assert dy.C == cpad(self.cout) and dx.C == cpad(self.cin) and dy.B == dx.B
         ops, k, p = self.ctx.ops, self.k, self.p
+        self.chain_parts = 0
+        assert chain is None or (self.s == 1 and not self.transposed and padded_domain and mask is None)
         if self.transposed:  # regular strided conv over dy
             pk = self.dgrad_pack
             assert dy.halo >= p and (dy.H, dy.W) == (2 * dx.H, 2 * dx.W) and not padded_domain
@@ -335,9 +340,29 @@ class ConvLayer:
             call = pk.finalize(ConvCall(dy.B, gh, gw, pk.cred, pk.ntaps, pk.nw, min(pk.nw, dx.C), dy, iy, iy, 1, 1, pk.tapoff(dy.Wp), None,
                                         None, dx, oy, oy, 1, 1, ACT_NONE, mask, mask.halo if mask else 0, mask.halo if mask else 0, pk.max_tapoff(dy.Wp)))
             call.alg_pixels = dy.H * dy.W      # the reference op's M is the forward output (dy) pixel count, not the (padded) input domain
+            if chain is not None:
+                opd = chain["operand"]
+                assert opd.C == dx.C and opd.B == dx.B and (opd.H, opd.W) == (dx.H, dx.W) and opd.halo == p
+                call.mask, call.mask_y0, call.mask_x0 = opd, 0, 0
+                call.stats, call.stats_mode = chain["ws"], 1
+                n = ops.conv_stats_parts(call) if call.w_frag else 0
+                if n <= 0 or dy.B * n * dx.C * 2 > chain["ws"].numel():
+                    raise GanError(f"input gradient B{dy.B} {gh}x{gw} C{dx.C}: the launch cannot carry the backward chain (ask can_chain first)")
+                self.chain_parts = n
             return [ops.conv_igemm(call)]
         assert not padded_domain and (dx.H, dx.W) == (2 * dy.H, 2 * dy.W)
         return self._phased(self.dgrad_packs, dy, dx, ACT_NONE, None, mask)
+
+    def can_chain(self, dy: View, dx: View) -> bool:
+        """True if dgrad(dy, dx, padded_domain=True, chain=...) is possible: a stride-1 layer in bf16 whose padded-domain input gradient
+        runs on the range-patch kernel (its epilogue carries the sums and the addend)."""
+        if self.transposed or self.s != 1 or self.ctx.dtype != BF16 or dx.halo != self.p or dy.halo < self.k - 1:
+            return False
+        try:      # planning only: dx stands in for the operand (same geometry), nothing is launched
+            self.dgrad(dy, dx, padded_domain=True, chain={"operand": dx, "ws": self.ctx.scratch("bwd_parts_a", dx.B * 96 * dx.C * 2)})
+        except GanError:
+            return False
+        return self.chain_parts > 0
 
     # ------------------------------------------------------------------ weight gradient
     def _nsplit(self, m: int, jtiles: int, ntiles: int, ntiles_skinny: bool = False) -> int:

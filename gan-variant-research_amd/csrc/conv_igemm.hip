@@ -220,6 +220,7 @@ extern "C" int gan_conv_igemm(const gan_conv_desc* d, void* stream) {
   GAN_CHECK(d->in && d->w && d->out && d->tapoff, "conv: null pointer");
   GAN_CHECK(((uintptr_t)d->in % 16) == 0 && ((uintptr_t)d->w % 16) == 0 && ((uintptr_t)d->out % 16) == 0, "conv: pointers must be 16-byte aligned");
   GAN_CHECK(d->stats == nullptr || d->w_layout == 1 || d->w_layout == 2, "conv: fused statistics exist only on the range-patch and 7x7 window paths (gan_conv_stats_parts)");
+  GAN_CHECK(d->stats_mode == 0 || d->w_layout == 1, "conv: stats_mode 1 exists only on the range-patch path (gan_conv_patch_ok)");
   const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
   GAN_CHECK(M < (1ll << 31), "conv: M too large");
   const int64_t in_bytes = (int64_t)d->B * d->in_Hp * d->in_Wp * d->Cin * es;

@@ -44,6 +44,7 @@ struct PatchArgs {
   int tapdiv;                   // tapoff[] / tapdiv = pixel offset of a tap (the operand's REAL channel count; Cin counts 2-byte slots)
   const float* w_scale; const float* in_scale;   // FP8: dequantisation scales (weights: one float; input: per image or NULL)
   float* stats;                 // optional per-tile InstanceNorm partials [B][MT_img][out_C][2] (sum, sum of squares), plain stores
+  int smode;                    // statistics mode (gan_conv_desc.stats_mode)
   unsigned long long* stamps;   // diagnostic build only (GAN_PATCH_STAMPS): [block][32] s_memtime stamps of wave 0
 };
 
@@ -101,8 +102,11 @@ __device__ __forceinline__ TileGeo tile_geo(const PatchArgs& a, int tau) {
 // moved the fp8 MFMA takes the cycles of the two bf16 MFMAs it replaces: twice the FLOPs per byte, HBM and LDS traffic halved.
 typedef __attribute__((ext_vector_type(8))) int v8i_t;
 typedef __attribute__((ext_vector_type(4))) int v4i_t;
-template <int BM, int WGN, int NT, bool FP8 = false, int NS = 7, int BN = 128>
+// EPI: 0 = the forward / plain input-gradient epilogues; 1 = the backward-chain epilogue (gan_conv_desc.stats_mode 1) -- kernels of their
+// own, so that it does not cost the other instantiations a register.
+template <int BM, int WGN, int NT, bool FP8 = false, int NS = 7, int BN = 128, int EPI = 0>
 __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
+  static_assert(EPI == 0 || (!FP8 && NT == 0), "backward-chain epilogues: bf16, generic tap loop");
   static_assert(!FP8 || NT == 0, "the fp8 path uses the generic tap loop");
   static_assert(BN == 128 || (BN == 256 && WGN == 4 && NT == 0 && !FP8), "256-channel tiles: 2 x 4 waves, generic tap loop, bf16");
   static_assert(NS == 7 || BM == 256, "the 9-slice buffers exist for the 256-row tile only");
@@ -671,13 +675,113 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
         __syncthreads();   // stsh is rewritten by the next tile
       }
     };
+    // ---- backward-chain epilogue (EPI == 1; gan_conv_desc.stats_mode 1): besides the padded-domain input gradient it leaves the two sums the
+    // InstanceNorm backward behind a ReLU needs, sum g [y > 0] and sum g y, y = the saved activation at the output pixel's own position.
+    // y comes from HBM (written a whole forward pass ago): fetched two pixel groups ahead of its use the loads were latency-bound (49 k cycles
+    // per tile against 8 k for the plain epilogue).  So the epilogue runs in two passes: pass A rounds a pixel group's accumulators to bf16
+    // (16 registers become 8), stores them, and issues the group's y quads into the 8 registers that freed -- after it ALL of the tile's y
+    // loads are in flight at no extra register; pass B walks the groups again and sums from the rounded gradient (what the consumer will
+    // read) and y.  The per-tile partials are summed over the same pixel groups in the same order at either tile width.
+    auto epilogue_chain = [&]() {
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      const int fr = lane_o & 15, fg = lane_o >> 4;
+      const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.mask, 0, a.mask_bytes, 0x00020000);
+      constexpr int HS = (BN == 256 && BM == 256) ? 2 : 1, FH = FI / HS;
+      u32x2_t pk[FI][FJ], yq[FI][FJ];
+#pragma unroll
+      for (int i = 0; i < FI; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int m = g.m0 + wm * (16 * FI) + i * 16 + fr;
+        const bool mok = m < a.M_img;
+        const int mm = mok ? m : a.M_img - 1;
+        const int ho = (int)__umulhi((uint32_t)mm, a.wo_magic), wo = mm - ho * a.Wo;
+        uint32_t ob = (uint32_t)(((g.b * a.out_Hp + ho * a.out_sy + a.out_y0) * a.out_Wp + wo * a.out_sx + a.out_x0) * a.out_C);
+        uint32_t mb = (uint32_t)(((g.b * a.mask_Hp + ho * a.out_sy + a.mask_y0) * a.mask_Wp + wo * a.out_sx + a.mask_x0) * a.out_C);
+        asm volatile("" : "+v"(ob), "+v"(mb));      // computed here, not inside a branch on `mok` (a join costs a conservative wait)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+          pk[i][j][0] = (uint32_t)f2bf(acc[i][j][0]) | ((uint32_t)f2bf(acc[i][j][1]) << 16);
+          pk[i][j][1] = (uint32_t)f2bf(acc[i][j][2]) | ((uint32_t)f2bf(acc[i][j][3]) << 16);
+        }
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+          const int n = g.n0 + wn * (16 * FJ) + j * 16 + fg * 4;
+          yq[i][j] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(mrsrc, n < a.Nst ? (int)((mb + (uint32_t)n) * 2u) : (int)0xfffffff0u, 0, 0));
+        }
+#pragma unroll
+        for (int jp = 0; jp < FJ / 2; ++jp) {
+          const auto ra = __builtin_amdgcn_permlane16_swap(pk[i][2 * jp][0], pk[i][2 * jp + 1][0], false, false);
+          const auto rb = __builtin_amdgcn_permlane16_swap(pk[i][2 * jp][1], pk[i][2 * jp + 1][1], false, false);
+          const u32x4_t st = {ra[0], rb[0], ra[1], rb[1]};
+          const int nst = g.n0 + wn * (16 * FJ) + (2 * jp + (fg & 1)) * 16 + (fg & 2) * 4;
+          const uint32_t off = (mok && nst < a.Nst) ? (ob + (uint32_t)nst) * 2u : 0xfffffff0u;
+          __builtin_amdgcn_raw_buffer_store_b128(st, orsrc, (int)off, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < HS; ++h) {
+        float ssum[4 * FJ], ssq[4 * FJ];
+#pragma unroll
+        for (int q = 0; q < 4 * FJ; ++q) ssum[q] = ssq[q] = 0.f;
+#pragma unroll
+        for (int i = h * FH; i < (h + 1) * FH; ++i) {
+          __builtin_amdgcn_sched_barrier(0);
+          const bool mok = g.m0 + wm * (16 * FI) + i * 16 + fr < a.M_img;
+#pragma unroll
+          for (int j = 0; j < FJ; ++j) {
+            const u32x2_t gq = pk[i][j], y2 = yq[i][j];
+            const float gv[4] = {__builtin_bit_cast(float, gq[0] << 16), __builtin_bit_cast(float, gq[0] & 0xffff0000u),
+                                 __builtin_bit_cast(float, gq[1] << 16), __builtin_bit_cast(float, gq[1] & 0xffff0000u)};
+            const float yv[4] = {__builtin_bit_cast(float, y2[0] << 16), __builtin_bit_cast(float, y2[0] & 0xffff0000u),
+                                 __builtin_bit_cast(float, y2[1] << 16), __builtin_bit_cast(float, y2[1] & 0xffff0000u)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float tm = mok ? gv[e] : 0.f;
+              ssum[4 * j + e] += yv[e] > 0.f ? tm : 0.f;
+              ssq[4 * j + e] += tm * yv[e];
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4 * FJ; ++q) asm volatile("" : "+v"(ssum[q]), "+v"(ssq[q]));   // pinned: hipcc otherwise sinks the sums below the loop and keeps every group alive
+        }
+#pragma unroll
+        for (int q = 0; q < 4 * FJ; ++q) { ssum[q] = row16_sum(ssum[q]); ssq[q] = row16_sum(ssq[q]); }
+        if (fr == 0) {
+#pragma unroll
+          for (int q = 0; q < 4 * FJ; ++q) {
+            const int ch = (q >> 2) * 16 + fg * 4 + (q & 3);           // channel inside this wave's 16*FJ
+            *reinterpret_cast<float2*>(stsh + ((((wm * HS + h) * WGN + wn) * (16 * FJ) + ch) << 1)) = make_float2(ssum[q], ssq[q]);
+          }
+        }
+      }
+      __syncthreads();
+      constexpr int WM = 8 / WGN * HS;
+      if (tid < BN) {
+        const int cwn = tid / (16 * FJ), cch = tid % (16 * FJ);
+        float2 tot = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+          const float2 v2 = *reinterpret_cast<const float2*>(stsh + (((m * WGN + cwn) * (16 * FJ) + cch) << 1));
+          tot.x += v2.x; tot.y += v2.y;
+        }
+        const int n = g.n0 + tid;
+        if (n < a.Nst)
+          *reinterpret_cast<float2*>(a.stats + (((int64_t)g.b * a.MT_img + g.m0 / BM) * a.out_C + n) * 2) = tot;
+      }
+      __syncthreads();   // stsh is rewritten by the next tile
+    };
     using std::integral_constant;
-    if (a.mask) epilogue(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, true>{}, integral_constant<bool, false>{});   // LeakyReLU' masks only follow plain dgrads
-    else if (a.act == GAN_ACT_NONE && a.stats) epilogue(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, false>{}, integral_constant<bool, true>{});
-    else if (a.act == GAN_ACT_NONE) epilogue(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
-    else if (a.act == GAN_ACT_LRELU) epilogue(integral_constant<int, GAN_ACT_LRELU>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
-    else if (a.act == GAN_ACT_RELU) epilogue(integral_constant<int, GAN_ACT_RELU>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
-    else epilogue(integral_constant<int, GAN_ACT_TANH>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
+    if constexpr (EPI == 1) epilogue_chain();
+    else {
+      if (a.mask) epilogue(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, true>{}, integral_constant<bool, false>{});   // LeakyReLU' masks only follow plain dgrads
+      else if (a.act == GAN_ACT_NONE && a.stats) epilogue(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, false>{}, integral_constant<bool, true>{});
+      else if (a.act == GAN_ACT_NONE) epilogue(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
+      else if (a.act == GAN_ACT_LRELU) epilogue(integral_constant<int, GAN_ACT_LRELU>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
+      else if (a.act == GAN_ACT_RELU) epilogue(integral_constant<int, GAN_ACT_RELU>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
+      else epilogue(integral_constant<int, GAN_ACT_TANH>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
+    }
 
     stamp();
     if (!has_next) break;
@@ -688,6 +792,8 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
 
 template <int BM, int WGN, int NT, bool FP8 = false, int NS = 7, int BN = 128>
 __global__ __launch_bounds__(NTHR) void conv_patch_kernel(PatchArgs a) { conv_patch_body<BM, WGN, NT, FP8, NS, BN>(a); }
+template <int BM, int WGN, int NS, int BN>
+__global__ __launch_bounds__(NTHR) void conv_patch_bwdchain_kernel(PatchArgs a) { conv_patch_body<BM, WGN, 0, false, NS, BN, 1>(a); }
 // The fp8 variants take all 256 registers (two 32-byte weight sets, one activation set, 64 accumulators and the compiler's scheduling
 // slack), so nothing of another stream runs beside them.  Capping them (`amdgpu_num_vgpr(108)`: on gfx90a+ the request is doubled, a
 // request of 216 is silently dropped) was measured: 216 registers = 304 bytes of scratch per lane inside the tap loop, 3x slower.
@@ -785,7 +891,8 @@ extern "C" int gan_conv_patch_tile_cols(const gan_conv_desc* d) {
 int gan_conv_win7_stats_parts(const gan_conv_desc* d);
 extern "C" int gan_conv_stats_parts(const gan_conv_desc* d) {
   if (d && d->w_layout == 2) return gan_conv_win7_stats_parts(d);
-  if (!gan_conv_patch_ok(d) || d->act != GAN_ACT_NONE || d->mask || d->out_sy != 1 || d->out_sx != 1) return 0;
+  if (!gan_conv_patch_ok(d) || d->act != GAN_ACT_NONE || (d->mask && d->stats_mode == 0) || d->out_sy != 1 || d->out_sx != 1) return 0;
+  if (d->stats_mode != 0 && (d->dtype != GAN_BF16 || !d->mask || d->stats_mode != 1 || d->bias)) return 0;
   const int BM = patch_tile_rows(d);
   return (d->Ho * d->Wo + BM - 1) / BM;
 }
@@ -799,7 +906,8 @@ static int patch_variant(const gan_conv_desc* d) {
   const bool fp8 = d->dtype == GAN_FP8;
   const int slots = fp8 ? d->Cin / 2 : d->Cin;
   const bool wide = BM == 256 && patch_span(d, 256) > RMAX;      // needs the 9-slice buffers (maps wider than 64 pixels)
-  const bool st9 = !fp8 && BN == 128 && BM == 256 && !wide && d->ntaps == 9 && (slots / 64) % 2 == 0 && !static_off;
+  const bool chain = d->stats_mode != 0;      // backward-chain epilogue: generic tap loop
+  const bool st9 = !fp8 && !chain && BN == 128 && BM == 256 && !wide && d->ntaps == 9 && (slots / 64) % 2 == 0 && !static_off;
   return BM | (BN << 12) | ((wide ? 9 : 7) << 24) | ((fp8 ? 1 : 0) << 28) | ((st9 ? 1 : 0) << 29);
 }
 extern "C" int gan_conv_patch_variant(const gan_conv_desc* d) { return gan_conv_patch_ok(d) ? patch_variant(d) : 0; }
@@ -829,7 +937,16 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   a.in_pix = d->B * d->in_Hp * d->in_Wp;
   a.out_Hp = d->out_Hp; a.out_Wp = d->out_Wp; a.out_C = d->out_C; a.out_y0 = d->out_y0; a.out_x0 = d->out_x0; a.out_sy = d->out_sy; a.out_sx = d->out_sx;
   a.Nst = d->Nst; a.act = d->act; a.stats = d->stats;
-  if (d->stats && (d->act != GAN_ACT_NONE || d->mask)) return gan_set_error(-1, "conv: fused statistics need act = none and no mask");
+  if (d->stats && (d->act != GAN_ACT_NONE || (d->mask && d->stats_mode == 0))) return gan_set_error(-1, "conv: fused statistics need act = none and no mask");
+  // backward-chain epilogue (gan_conv_desc.stats_mode 1): bf16 operands, plain result of an input gradient (no bias)
+  a.smode = d->stats ? d->stats_mode : 0;
+  if (d->stats_mode != 0) {
+    if (d->stats_mode != 1) return gan_set_error(-1, "conv: stats_mode %d (0 | 1)", d->stats_mode);
+    if (d->dtype != GAN_BF16 || d->act != GAN_ACT_NONE || d->out_sy != 1 || d->out_sx != 1 || d->bias)
+      return gan_set_error(-1, "conv: stats_mode 1 needs bf16 operands, act = none, no bias and a dense output");
+    if (!d->stats || !d->mask) return gan_set_error(-1, "conv: stats_mode 1 needs stats and its operand (mask)");
+    if (d->mask_y0 + d->Ho > d->mask_Hp || d->mask_x0 + d->Wo > d->mask_Wp) return gan_set_error(-1, "conv: stats_mode 1: the operand does not cover the output domain");
+  }
   a.mask_Hp = d->mask_Hp; a.mask_Wp = d->mask_Wp; a.mask_y0 = d->mask_y0; a.mask_x0 = d->mask_x0;
   // diagnostic environment (stamp buffer, static-schedule switch): read once per process, not per launch
   static unsigned long long* const stamps_env = [] { const char* e = getenv("GAN_PATCH_STAMPS"); return e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }();
@@ -846,7 +963,10 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
         !raise((const void*)conv_patch_kernel<256, 2, 9>, lds_bytes(7)) || !raise((const void*)conv_patch_fp8_kernel, lds_bytes(7)) ||
         !raise((const void*)conv_patch_kernel<256, 2, 0, false, 9>, lds_bytes(9)) || !raise((const void*)conv_patch_fp8_wide_kernel, lds_bytes(9)) ||
         !raise((const void*)conv_patch_kernel<256, 4, 0, false, 7, 256>, lds_bytes(7)) || !raise((const void*)conv_patch_kernel<288, 4, 0, false, 7, 256>, lds_bytes(7)) ||
-        !raise((const void*)conv_patch_kernel<256, 4, 0, false, 9, 256>, lds_bytes(9)))
+        !raise((const void*)conv_patch_kernel<256, 4, 0, false, 9, 256>, lds_bytes(9)) ||
+        !raise((const void*)conv_patch_bwdchain_kernel<256, 2, 7, 128>, lds_bytes(7)) || !raise((const void*)conv_patch_bwdchain_kernel<288, 4, 7, 128>, lds_bytes(7)) ||
+        !raise((const void*)conv_patch_bwdchain_kernel<256, 2, 9, 128>, lds_bytes(9)) || !raise((const void*)conv_patch_bwdchain_kernel<256, 4, 7, 256>, lds_bytes(7)) ||
+        !raise((const void*)conv_patch_bwdchain_kernel<288, 4, 7, 256>, lds_bytes(7)) || !raise((const void*)conv_patch_bwdchain_kernel<256, 4, 9, 256>, lds_bytes(9)))
       return gan_set_error(-2, "conv_patch: cannot raise the dynamic LDS limit to %d bytes", lds_bytes(9));
     attr_devs.fetch_or(dev_bit, std::memory_order_release);
   }
@@ -854,7 +974,18 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   // stream clocks lower (2.04 -> 1.88 GHz), so the forward gains 3 % wall (69.5 -> 67.2 us = 1.15 PFLOP/s); on the 288-row tile,
   // whose 9 fragment addresses per tap do not fit in registers, it lost 9 % and is not instantiated.
   const bool wide = ((variant >> 24) & 0xf) == 9, st9 = (variant >> 29) & 1;
-  if (fp8) {
+  if (a.smode != 0) {
+    if (BN == 256) {
+      if (BM == 256 && wide) hipLaunchKernelGGL((conv_patch_bwdchain_kernel<256, 4, 9, 256>), dim3(grid), dim3(NTHR), lds_bytes(9), s, a);
+      else if (BM == 256) hipLaunchKernelGGL((conv_patch_bwdchain_kernel<256, 4, 7, 256>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
+      else hipLaunchKernelGGL((conv_patch_bwdchain_kernel<288, 4, 7, 256>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
+    } else if (BM == 256) {
+      if (wide) hipLaunchKernelGGL((conv_patch_bwdchain_kernel<256, 2, 9, 128>), dim3(grid), dim3(NTHR), lds_bytes(9), s, a);
+      else hipLaunchKernelGGL((conv_patch_bwdchain_kernel<256, 2, 7, 128>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
+    } else {
+      hipLaunchKernelGGL((conv_patch_bwdchain_kernel<288, 4, 7, 128>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
+    }
+  } else if (fp8) {
     if (wide) hipLaunchKernelGGL(conv_patch_fp8_wide_kernel, dim3(grid), dim3(NTHR), lds_bytes(9), s, a);
     else hipLaunchKernelGGL(conv_patch_fp8_kernel, dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
   } else if (BN == 256) {

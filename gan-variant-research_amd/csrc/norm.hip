@@ -406,7 +406,7 @@ __global__ __launch_bounds__(NTHR, 6) void in_bwd_partial_kernel(DView x, const 
 // AMAX: additionally amax[b] = max(amax[b], max |dx| of this block) (atomic max on the bit patterns of non-negative floats: order-independent).
 template <typename T, int UNR, int ACT, bool FOLD, bool AMAX = false>
 __global__ __launch_bounds__(NTHR, 6) void in_bwd_apply_kernel(DView x, const float* __restrict__ stats, DView gy, const float* __restrict__ ws, int nch,
-                                                           DView dx, int nblk, float* __restrict__ bias_part, float* __restrict__ amax = nullptr) {
+                                                           DView dx, int nblk, float* __restrict__ bias_part, float* __restrict__ amax = nullptr, int s2_xhat = 0) {
   constexpr int N = Chunk<T>::N, NP = Pairs<T>::NP;
   Lanes<T> L(x.C);
   const int b = blockIdx.y, HW = x.H * x.W, cofs = L.cl * N;
@@ -419,7 +419,8 @@ __global__ __launch_bounds__(NTHR, 6) void in_bwd_apply_kernel(DView x, const fl
 #pragma unroll 8
     for (int k = 0; k < nch; ++k) { const float2 t = pp[(int64_t)k * x.C]; S1 += t.x; S2 += t.y; }
     const double mu = stats[((int64_t)b * x.C + c) * 2], rs = stats[((int64_t)b * x.C + c) * 2 + 1];
-    const double m1 = S1 / HW, m2 = rs * (S2 - mu * S1) / HW;
+    // s2_xhat: the second sum was taken against xhat itself (an input-gradient epilogue summing g * relu(xhat), gan_conv_desc.stats_mode 1)
+    const double m1 = S1 / HW, m2 = s2_xhat ? S2 / HW : rs * (S2 - mu * S1) / HW;
     const double bcd = -rs * rs * m2, ccd = -rs * m1 + rs * rs * m2 * mu;
     const f32x4_t r = {(float)mu, (float)rs, (float)bcd, (float)ccd};
     sh4[c] = r;
@@ -938,6 +939,44 @@ extern "C" int gan_in_bwd_amax(const gan_view* x, const float* stats, int act, c
   GAN_CHECK(amax, "in_bwd_amax: null amax");
   if (hipMemsetAsync(amax, 0, sizeof(float) * (x ? x->B : 0), (hipStream_t)stream) != hipSuccess) return gan_set_error(-2, "in_bwd_amax: memset failed");
   return in_bwd_impl(x, stats, act, gy, fold, nullptr, dx, ws, nullptr, 0, 0, stream, bias_part, amax);
+}
+
+// The apply pass alone: the two sums per (image, channel) come as partials from the launch that produced gy (an input-gradient epilogue,
+// gan_conv_desc.stats_mode 1 | 2), so x and gy are read once instead of twice.
+extern "C" int gan_in_bwd_parts(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* dx, const float* parts,
+                                int nparts, int parts_mode, float* bias_part, void* stream) {
+  VCHK(x, "in_bwd_parts.x"); VCHK(gy, "in_bwd_parts.gy"); VCHK(dx, "in_bwd_parts.dx");
+  if (check_lanes(x, "in_bwd_parts")) return -1;
+  SAME_SHAPE(x, gy, "in_bwd_parts(x,gy)"); SAME_SHAPE(x, dx, "in_bwd_parts(x,dx)");
+  if (fold_ok(gy, fold)) return -1;
+  GAN_CHECK(stats && parts, "in_bwd_parts: null pointer");
+  GAN_CHECK(nparts >= 1 && nparts <= MAXCH, "in_bwd_parts: nparts=%d outside 1..%d", nparts, MAXCH);
+  GAN_CHECK(parts_mode == 1 || parts_mode == 2, "in_bwd_parts: parts_mode %d (1: sums against xhat, 2: against the raw x)", parts_mode);
+  GAN_CHECK(act == GAN_ACT_NONE || act == GAN_ACT_RELU || act == GAN_ACT_LRELU, "in_bwd_parts: unsupported activation %d", act);
+  GAN_CHECK(parts_mode != 1 || act == GAN_ACT_RELU, "in_bwd_parts: sums against relu(xhat) belong to a ReLU'd norm");
+  GAN_CHECK(x->C <= NTHR * 8 / 4, "in_bwd_parts: C=%d > %d", x->C, NTHR * 8 / 4);
+  const int HW = x->H * x->W, nblk = nblocks_for(HW, lanes_of(x));
+  DView vx = to_dview(x), vg = to_dview(gy), vd = to_dview(dx);
+  hipStream_t s = (hipStream_t)stream;
+  const int xh = parts_mode == 1 ? 1 : 0;
+  GAN_DISPATCH_NORM(x->dtype,
+    auto go = [&](auto act_c, auto fold_c) {
+      constexpr int ACT = decltype(act_c)::value;
+      constexpr bool FOLD = decltype(fold_c)::value;
+      hipLaunchKernelGGL((in_bwd_apply_kernel<T, U, ACT, FOLD>), dim3(nblk, x->B), dim3(NTHR), 0, s, vx, stats, vg, parts, nparts, vd, nblk, bias_part, (float*)nullptr, xh);
+    };
+    using std::integral_constant;
+    if (fold) {
+      if (act == GAN_ACT_RELU) go(integral_constant<int, GAN_ACT_RELU>{}, integral_constant<bool, true>{});
+      else if (act == GAN_ACT_LRELU) go(integral_constant<int, GAN_ACT_LRELU>{}, integral_constant<bool, true>{});
+      else go(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, true>{});
+    } else {
+      if (act == GAN_ACT_RELU) go(integral_constant<int, GAN_ACT_RELU>{}, integral_constant<bool, false>{});
+      else if (act == GAN_ACT_LRELU) go(integral_constant<int, GAN_ACT_LRELU>{}, integral_constant<bool, false>{});
+      else go(integral_constant<int, GAN_ACT_NONE>{}, integral_constant<bool, false>{});
+    })
+  GAN_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int gan_bias_finalize_batch(const gan_bias_part_desc* descs, int n, int total_blocks, void* stream) {

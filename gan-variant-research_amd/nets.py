@@ -263,9 +263,20 @@ class GPass:
         if not hasattr(self, "_bias_parts"):
             self._bias_parts = {}
 
-        def inbwd(raw, stats, act, gy, fold, dx, conv=None, amax=None):
+        def inbwd(raw, stats, act, gy, fold, dx, conv=None, amax=None, parts=None):
             """InstanceNorm backward; with `conv`, its bias gradient (column sums of dx) comes out of the same pass; with `amax`, max|dx|
-            per image too (the scale of dx's e4m3 copy)."""
+            per image too (the scale of dx's e4m3 copy); with `parts` = (ws, nparts, mode) the two sums were written by the producer of gy
+            (an input-gradient epilogue, ConvLayer.dgrad(chain=...)) and only the apply half runs."""
+            if parts is not None:
+                part = None
+                if conv is not None and conv.grad_b is not None:
+                    nparts = ops.in_bwd_bias_parts(raw)
+                    part = self._bias_parts.get(id(conv))
+                    if part is None:
+                        part = self._bias_parts[id(conv)] = ctx.f32(nparts * raw.C)
+                    bias_items.append((part, nparts, raw.C, conv.grad_b, conv.cout, acc))
+                prog.add(ops.in_bwd_parts(raw, stats, act, gy, fold, dx, parts[0], parts[1], parts[2], part))
+                return
             if amax is not None:
                 part = None
                 if conv is not None and conv.grad_b is not None:
@@ -290,6 +301,14 @@ class GPass:
         i = self.last
         g_cur: Optional[View] = None   # gradient wrt acts[i]
         g_fold = False
+        # Backward chain of the residual blocks (bf16, reflect padding, ReLU blocks): the input gradient of a block's second convolution
+        # leaves the two sums of the ReLU'd norm's backward in its epilogue (ConvLayer.dgrad(chain=...)); gan_in_bwd_parts then applies
+        # with x and g read once -- one of the five HBM-bound passes per block is gone (DESIGN 3.6 has what else was built and measured).
+        use_chain = False
+        if self.last >= 3 and ctx.dtype == BF16 and rf and not net.fp8 and net.block_act == ACT_RELU and not os.environ.get("GAN_NO_BWD_CHAIN"):
+            r0 = self.raw[3][0]
+            use_chain = net.c_blk[0][1].can_chain(net.gbuf("dy_blk_b0", B, r0.H, r0.W, r0.C, 2), net.gbuf("g_blk_p", B, r0.H, r0.W, r0.C, 1))
+        self.bwd_chain = use_chain
         if self.full:
             assert g_img is not None
             dyo = net.gbuf("dy_out", B, H, W, self.img.C, 6)
@@ -325,6 +344,7 @@ class GPass:
             dyb = net.gbuf(f"dy_blk_b{k % 2}", B, h4, w4, c4, 2)   # two sets, alternating: the side stream reads them one block late
             before_write(dyb)
             g_mid = net.gbuf("g_blk_p", B, h4, w4, c4, 1)
+            a_parts = None
             if net.fp8:
                 # input gradients on e4m3 operands: the norm backward leaves max|dY| per image, the copy is scaled by it
                 dy8, am8, sc8 = self._fp8_grad_bufs(B, h4, w4, c4)
@@ -335,7 +355,12 @@ class GPass:
             else:
                 inbwd(rb, sb, ACT_NONE, g_cur, False, dyb, cb)
                 wgrad_side(cb, self.mid[k], dyb, False)
-                prog.add(cb.dgrad(dyb, g_mid, padded_domain=rf))
+                if use_chain:      # the epilogue also sums for the ReLU'd norm, whose saved output mid[k] carries the reflect halo
+                    pa = ctx.scratch("bwd_parts_a", B * IN_WS_CHUNKS * c4 * 2)
+                    prog.add(cb.dgrad(dyb, g_mid, padded_domain=True, chain={"operand": self.mid[k], "ws": pa}))
+                    a_parts = (pa, cb.chain_parts, 1)
+                else:
+                    prog.add(cb.dgrad(dyb, g_mid, padded_domain=rf))
             dya = net.gbuf(f"dy_blk_a{k % 2}", B, h4, w4, c4, 2)
             before_write(dya)
             g_in_p = net.gbuf("g_blk_p", B, h4, w4, c4, 1)
@@ -345,7 +370,7 @@ class GPass:
                 prog.add(ops.quantize_fp8(dya, dy8, am8, sc8))
                 prog.add(ca.dgrad8(dy8, g_in_p, sc8, padded_domain=rf))
             else:
-                inbwd(ra, sa, net.block_act, g_mid, rf, dya, ca)
+                inbwd(ra, sa, net.block_act, g_mid, rf, dya, ca, parts=a_parts)
                 wgrad_side(ca, self.acts[i - 1], dya, False)
                 prog.add(ca.dgrad(dya, g_in_p, padded_domain=rf))
             g_next = net.gbuf(f"g_res{k % 2}", B, h4, w4, c4, 0)

@@ -100,6 +100,7 @@ class ConvCall:
     win7: Optional[tuple] = None           # (ty0, tx0): run by the 7x7 window kernel, taps row-major from that position (w_layout 2)
     w_scale: Optional[torch.Tensor] = None  # fp8 operands: device float, dequantisation scale of the weight copy
     in_scale: Optional[torch.Tensor] = None  # fp8 operands: device float[B], per-image scale of the input copy (None: 1)
+    stats_mode: int = 0                    # 0: forward statistics; 1: backward chain, (sum t [m > 0], sum t m) with m = `mask` at the pixel (gan_conv_desc)
     flop_scale: float = 1.0                # algorithmic / launched FLOPs (paired phases multiply by zero blocks: 0.75); bench.py prices with it
     alg_pixels: Optional[int] = None       # output pixels per image of the REFERENCE op this launch implements, when they differ from Ho*Wo
                                            # (stride-1 input gradients run on the input's -- possibly reflect-padded -- domain); SURVEY §8d
@@ -137,6 +138,7 @@ class WgradCall:
 
 
 Op = Callable[[], None]
+
 
 
 class Program:
@@ -280,6 +282,7 @@ class HipOps:
             assert c.mask.C == c.out.C and c.mask.dtype == c.out.dtype
             d.mask, d.mask_Hp, d.mask_Wp, d.mask_y0, d.mask_x0 = c.mask.ptr(), c.mask.Hp, c.mask.Wp, c.mask_y0, c.mask_x0
         d.stats = c.stats.data_ptr() if c.stats is not None else None
+        d.stats_mode = c.stats_mode
         d.max_tapoff = c.max_tapoff
         d.w_layout = 1 if c.w_frag else 0
         d.tile_rows, d.tile_cols = c.tile_rows, c.tile_cols
@@ -456,6 +459,14 @@ class HipOps:
         assert bias_part.dtype == torch.float32 and bias_part.numel() >= self.in_bwd_bias_parts(x) * x.C
         return self._hbm(self._call("gan_in_bwd_bias_deferred", self._v(x), self._p(stats), act, self._v(gy), int(fold), self._v(g2), self._v(dx),
                                     self._p(ws), self._p(bias_part), self._s()), x, 3 + (g2 is not None))
+
+    def in_bwd_parts(self, x: View, stats, act, gy: View, fold, dx: View, parts, nparts, parts_mode, bias_part=None) -> Op:
+        """The apply half of the InstanceNorm backward alone: the per-(image, channel) sums come as `nparts` partial pairs from the
+        input-gradient epilogue that wrote gy (ConvCall.stats_mode 1 | 2 = parts_mode)."""
+        assert parts.dtype == torch.float32 and parts.numel() >= x.B * nparts * x.C * 2
+        assert bias_part is None or bias_part.numel() >= self.in_bwd_bias_parts(x) * x.C
+        return self._hbm(self._call("gan_in_bwd_parts", self._v(x), self._p(stats), act, self._v(gy), int(fold), self._v(dx), self._p(parts), nparts,
+                                    parts_mode, self._p(bias_part), self._s()), x, 3)
 
     def bias_finalize_batch(self, items) -> Op:
         """items: (part, nparts, C, grad, N_real, accumulate) per layer -> one launch."""

@@ -79,6 +79,15 @@ typedef struct gan_conv_desc {
    * weight copy (gan_weight_scale_batch) and of image b of the input copy (gan_quantize_fp8), both device pointers. */
   const float* w_scale;
   const float* in_scale;
+  /* Backward chain of a residual block (range-patch kernel only, w_layout 1, bf16, act none, no bias; generator_resnet_attn.py:56,64):
+   * stats_mode 0: `stats` receives (sum t, sum t^2), the forward statistics of the result, and `mask` is the LeakyReLU' mask (as before);
+   * stats_mode 1: `stats` receives (sum t [m > 0], sum t m) -- the two sums the InstanceNorm backward behind a ReLU needs of its incoming
+   *   gradient t (this launch's result, an input gradient on the reflect-padded domain) -- with m = relu(xhat) = the activation the
+   *   forward saved WITH its reflect halo, named by `mask` and the mask_* geometry and read at the output pixel's own position; the mask
+   *   is then NOT applied to the result.  Summing on the padded domain equals summing the folded gradient because the halo of m is a copy
+   *   of its pre-image.  Same partial layout as mode 0 ([B][P][out_C][2], P = gan_conv_stats_parts); consumer: gan_in_bwd_parts. */
+  int32_t stats_mode;
+  int32_t _pad2;
 } gan_conv_desc;
 
 /* Weight-gradient GEMM: part[s][n][t][c] = sum over the rows m of split s of
@@ -207,6 +216,13 @@ typedef struct gan_bias_part_desc {
   int32_t nparts, C, N_real, accumulate, first_block, _pad;
 } gan_bias_part_desc;
 int gan_in_bwd_bias_parts(const gan_view* x);
+/* The apply half of gan_in_bwd_bias_deferred alone, for a gradient whose two per-(image, channel) sums were already produced by the launch
+ * that wrote it: parts = fp32 [B][nparts][C][2], 1 <= nparts <= 96, summed here in fp64 and in part order.
+ * parts_mode 1: (sum g', sum g' xhat), second sum in normalised units (gan_conv_desc.stats_mode 1: m = relu(xhat); act must be relu);
+ * parts_mode 2: (sum g', sum g' x) against the raw x (what gan_in_bwd's own first pass computes: for a producer that has x at hand).
+ * bias_part may be NULL. */
+int gan_in_bwd_parts(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* dx, const float* parts,
+                     int nparts, int parts_mode, float* bias_part, void* stream);
 int gan_in_bwd_bias_deferred(const gan_view* x, const float* stats, int act, const gan_view* gy, int fold, const gan_view* g2,
                              const gan_view* dx, float* ws, float* bias_part, void* stream);
 int gan_bias_finalize_batch(const gan_bias_part_desc* descs, int n, int total_blocks, void* stream);

@@ -142,7 +142,9 @@ class EmuOps:
         """Statement of gan_conv_stats_parts; the emulator reports one part per image."""
         if getattr(c, "win7", None) is not None:            # 7x7 window path: only the 3 -> 64 kernel writes partials
             return 1 if (c.Cin == 8 and c.Nst == 64 and c.act == ACT_NONE) else 0
-        return 1 if (self.conv_patch_ok(c) and c.act == ACT_NONE and c.mask is None and (c.out_sy, c.out_sx) == (1, 1)) else 0
+        if getattr(c, "stats_mode", 0) != 0 and (c.x.dtype != 1 or c.mask is None or c.stats_mode != 1 or c.bias is not None):
+            return 0
+        return 1 if (self.conv_patch_ok(c) and c.act == ACT_NONE and (c.mask is None or getattr(c, "stats_mode", 0) != 0) and (c.out_sy, c.out_sx) == (1, 1)) else 0
 
     def in_partial_count(self, x):
         """Statement of gan_in_partial_count; the emulator writes one partial per image."""
@@ -215,13 +217,21 @@ class EmuOps:
             v = acc[..., :c.Nst]
             if c.bias is not None:
                 v = v + c.bias[:c.Nst].float()
-            if getattr(c, "stats", None) is not None:   # fused InstanceNorm partials: one part per image here (any tiling sums to the same)
-                assert self.conv_stats_parts(c) == 1 and c.Nst == c.out.C
-                c.stats[:c.B * c.Nst * 2].view(c.B, 1, c.Nst, 2).copy_(torch.stack([v.sum((1, 2)), (v * v).sum((1, 2))], -1).unsqueeze(1))
-            v = _act(v, c.act)
             oy = c.out_y0 + torch.arange(c.Ho) * c.out_sy
             ox = c.out_x0 + torch.arange(c.Wo) * c.out_sx
-            if c.mask is not None:
+            smode = getattr(c, "stats_mode", 0)
+            if getattr(c, "stats", None) is not None:   # fused InstanceNorm partials: one part per image here (any tiling sums to the same)
+                assert self.conv_stats_parts(c) == 1 and c.Nst == c.out.C
+                if smode == 0:
+                    pair = [v.sum((1, 2)), (v * v).sum((1, 2))]
+                else:     # backward chain: sums of the rounded gradient against m = the saved ReLU output at the output pixel itself (halo included)
+                    assert smode == 1 and c.bias is None and c.act == ACT_NONE
+                    m = c.mask.padded().float()[:, c.mask_y0 + torch.arange(c.Ho)][:, :, c.mask_x0 + torch.arange(c.Wo)][..., :c.Nst]
+                    vr = v.to(c.out.padded().dtype).float()
+                    pair = [(vr * (m > 0)).sum((1, 2)), (vr * m).sum((1, 2))]
+                c.stats[:c.B * c.Nst * 2].view(c.B, 1, c.Nst, 2).copy_(torch.stack(pair, -1).unsqueeze(1))
+            v = _act(v, c.act)
+            if c.mask is not None and smode == 0:
                 my = c.mask_y0 + torch.arange(c.Ho) * c.out_sy
                 mx = c.mask_x0 + torch.arange(c.Wo) * c.out_sx
                 m = c.mask.padded().float()[:, my][:, :, mx][..., :c.Nst]
@@ -400,6 +410,29 @@ class EmuOps:
         def op():
             inner()
             bias_part[:x.B * x.C].view(x.B, x.C).copy_(dx.nhwc().float().sum((1, 2)))
+        return op
+
+    def in_bwd_parts(self, x, stats, act, gy, fold, dx, parts, nparts, parts_mode, bias_part=None):
+        """Statement of gan_in_bwd_parts: the apply half with the two sums taken from the producer's partials."""
+        def op():
+            st = stats.view(x.B, 1, 1, x.C, 2)
+            xh = (x.nhwc().float() - st[..., 0]) * st[..., 1]
+            g = _fold(gy, fold)
+            if act == ACT_RELU:
+                g = g * (xh > 0)
+            elif act == ACT_LRELU:
+                g = torch.where(xh > 0, g, 0.2 * g)
+            HW = x.H * x.W
+            S = parts[:x.B * nparts * x.C * 2].view(x.B, nparts, x.C, 2).double().sum(1)
+            m1 = (S[..., 0] / HW).float().view(x.B, 1, 1, x.C)
+            if parts_mode == 1:
+                m2 = (S[..., 1] / HW).float().view(x.B, 1, 1, x.C)
+            else:
+                mu, rs = stats.view(x.B, x.C, 2)[..., 0].double(), stats.view(x.B, x.C, 2)[..., 1].double()
+                m2 = (rs * (S[..., 1] - mu * S[..., 0]) / HW).float().view(x.B, 1, 1, x.C)
+            _store(dx, st[..., 1] * (g - m1 - xh * m2))
+            if bias_part is not None:
+                bias_part[:x.B * x.C].view(x.B, x.C).copy_(dx.nhwc().float().sum((1, 2)))
         return op
 
     def bias_finalize_batch(self, items):

@@ -167,3 +167,20 @@ def test_cut_step_with_fp8_block_convolutions_on_emulator():
     tr, img, ref = cases.run_cut_steps("cpu", EmuOps(), True, amp=True, S=32, B=2, nsteps=1, tol0=8e-2, ptol=4.5e-4, fp8=True)
     assert tr.fp8 and tr.G.fp8
     assert float((img - ref).abs().max()) < 0.3 and float((img - ref).pow(2).mean().sqrt()) < 0.06
+
+
+def test_cut_step_bf16_backward_chain_on_emulator(monkeypatch):
+    """The backward chain of the residual blocks (generator_resnet_attn.py:56,64,71 under autograd) as the bf16 trainer runs it: block
+    gradients kept on the padded domain, the skip path added and the InstanceNorm-backward sums left by the input-gradient epilogues
+    (ConvLayer.dgrad(chain=...), gan_in_bwd_parts).  Two steps against the fp32 oracle with the bf16 tolerance; and the summed generator
+    gradient of step 0 against the same step with the chain switched off (fold_add + two-pass norm backward): the two orders of
+    computation may differ by bf16 rounding only (measured 1.4 % of the gradient's norm; a wrong sum or a missing skip path is > 30 %)."""
+    tr, img, ref = cases.run_cut_steps("cpu", EmuOps(), True, amp=True, S=32, B=2, nsteps=2, tol0=4e-2, tol1=6e-2, atol1=2e-2, ptol=4.5e-4)
+    assert tr.p2.bwd_chain and all(m["p1"].bwd_chain for m in tr._modes.values() if m is not None)
+    assert float((img - ref).abs().max()) < 5e-2
+    tr1, _, _ = cases.run_cut_steps("cpu", EmuOps(), True, amp=True, S=32, B=2, nsteps=1, tol0=4e-2, ptol=4.5e-4)
+    monkeypatch.setenv("GAN_NO_BWD_CHAIN", "1")
+    tr2, _, _ = cases.run_cut_steps("cpu", EmuOps(), True, amp=True, S=32, B=2, nsteps=1, tol0=4e-2, ptol=4.5e-4)
+    assert tr1.p2.bwd_chain and not tr2.p2.bwd_chain
+    err = float((tr1.opt_G.flat_g - tr2.opt_G.flat_g).norm() / tr2.opt_G.flat_g.norm())
+    assert err < 3e-2, err

@@ -719,3 +719,52 @@ def test_multi_stream_step_is_deterministic(monkeypatch):
     lc, gc, dc = run()
     assert la == lc, (la, lc)
     assert torch.equal(ga, gc) and torch.equal(da, dc)
+
+
+@pytest.mark.parametrize("bn", ["128", "256"])
+@pytest.mark.parametrize("bm", ["256", "288"])
+@pytest.mark.parametrize("H", [16, 20])
+def test_conv_backward_chain_epilogue(bm, bn, H, monkeypatch):
+    """The backward-chain epilogue of the range-patch kernel (gan_conv_desc.stats_mode 1) against its CPU statement: the padded-domain
+    input gradient, and the per-image sums the InstanceNorm backward behind the ReLU needs (sum g [y > 0], sum g y) -- summed over the
+    kernel's tiles they must equal the emulator's single partial; both tile heights and widths, a map with a partial last tile
+    (22x22 = 484 pixels).  Then gan_in_bwd_parts on those partials against the two-pass gan_in_bwd on the same gradient."""
+    from gan_variant_research_amd.convplan import ConvLayer
+    from gan_variant_research_amd._lib import ACT_RELU
+    monkeypatch.setenv("GAN_PATCH_BM", bm)
+    monkeypatch.setenv("GAN_PATCH_BN", bn)
+    B, Cc = 3, 256
+    tw = Twin(BF16, seed=5)
+    dyc, dyg = tw.view(B, H, H, Cc, 2, zero_halo=True)
+    xc, xg = tw.view(B, H, H, Cc, 0)                                       # raw norm input
+    stc, stg = tw.f32(torch.stack([xc.nhwc().float().mean((1, 2)), 1.0 / torch.sqrt(xc.nhwc().float().var((1, 2), unbiased=False) + 1e-5)], -1).reshape(-1))
+    yc, yg = tw.view(B, H, H, Cc, 1, rand=False)                           # relu(xhat) with its reflect halo, as the forward saved it
+    outc, outg = tw.view(B, H, H, Cc, 1, rand=False)
+    d1c, d1g = tw.view(B, H, H, Cc, 2, rand=False)
+    d2c, d2g = tw.view(B, H, H, Cc, 2, rand=False)
+    w = torch.randn(Cc, Cc, 3, 3, generator=tw.gen) * 0.03
+    sums, parts = [], []
+    for ctx, dy, x, st, y, out, d1, d2 in ((tw.c, dyc, xc, stc, yc, outc, d1c, d2c), (tw.g, dyg, xg, stg, yg, outg, d1g, d2g)):
+        dev = ctx.device
+        from gan_variant_research_amd._lib import HALO_REFLECT
+        ctx.ops.in_apply(x, st, ACT_RELU, None, y, HALO_REFLECT)()
+        layer = ConvLayer(ctx, w.to(dev), None, torch.zeros_like(w).to(dev), None, 3, 1, 1)
+        ws = ctx.f32(B * 96 * Cc * 2)
+        ops = layer.dgrad(dy, out, padded_domain=True, chain={"operand": y, "ws": ws})
+        for o in layer.repack_ops() + ops:
+            o()
+        n = layer.chain_parts
+        parts.append(n)
+        sums.append(ws[:B * n * Cc * 2].view(B, n, Cc, 2).double().sum(1).cpu())
+        if ctx is tw.g:
+            v = ctx.ops.conv_patch_variant(ops[-1].conv)
+            assert v["rows"] == int(bm) and v["cols"] == int(bn), v
+        # the norm backward from the partials, and the two-pass one on the same gradient
+        ctx.ops.in_bwd_parts(x, st, ACT_RELU, out, True, d1, ws, n, 1)()
+        ctx.ops.in_bwd(x, st, ACT_RELU, out, True, None, d2, ctx.f32(B * 96 * Cc * 2 + B * Cc * 2 + (B * 1024 + 32) * Cc))()
+    torch.cuda.synchronize()
+    assert parts[1] == -(-(H + 2) * (H + 2) // int(bm))
+    tw.check(2e-2, 2e-2)
+    scale = sums[0].abs().max()
+    np.testing.assert_allclose(sums[1].numpy(), sums[0].numpy(), rtol=2e-2, atol=float(scale) * 2e-3)
+    np.testing.assert_allclose(d1g.t.float().cpu().numpy(), d2g.t.float().cpu().numpy(), rtol=2e-2, atol=2e-2)

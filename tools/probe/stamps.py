@@ -23,7 +23,14 @@ if mode == "fwd":
 else:
     dy = ctx.view(B, 64, 64, 256, 2); dy.t.normal_()
     dx = ctx.view(B, 64, 64, 256, 1)
-    ops = layer.dgrad(dy, dx, padded_domain=True)
+    chain = None
+    if mode == "chain":      # backward-chain epilogue (stats_mode 1); operands evicted between launches: cold, as in the step
+        opd = ctx.view(B, 64, 64, 256, 1); opd.t.normal_()
+        chain = {"operand": opd, "ws": ctx.f32(B * 96 * 256 * 2)}
+        layer.bias = layer.bias_k = None
+    ops = layer.dgrad(dy, dx, padded_domain=True, chain=chain)
+    flush = torch.empty(300 << 20, dtype=torch.uint8, device=dev)
+    ops = ops + [lambda: flush.zero_()]        # evict the operands between launches
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for _ in range(20):
     for o in ops: o()
