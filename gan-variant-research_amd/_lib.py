@@ -119,7 +119,8 @@ PROTOTYPES = {
     "gan_patchnce_ws_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "gan_patchnce_fwd": (C.c_int, [PV, PV, vp, C.c_int, C.c_int, f32, f32, vp, vp, vp]),
     "gan_patchnce_bwd": (C.c_int, [PV, vp, C.c_int, C.c_int, f32, f32, PV, vp, vp]),
-    "gan_adam_step": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, f32, f32, f32, f32, f32, f32, f32, vp, vp, vp]),
+    "gan_adam_step": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, f32, f32, f32, f32, f32, f32, f32, vp, vp, C.c_int, vp, vp, vp]),
+    "gan_scaler_update": (C.c_int, [vp, vp, vp, vp, f32, f32, C.c_int, vp]),
     "gan_fill_f32": (C.c_int, [vp, C.c_int64, f32, vp]),
     "gan_axpy_f32": (C.c_int, [vp, vp, f32, C.c_int64, vp]),
 }

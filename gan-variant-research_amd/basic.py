@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from ._lib import BF16, F32, HALO_ZERO
-from .cut import FusedAdam
+from .cut import FusedAdam, _adam_state_dict, _load_adam_state_dict
 from .nets import DiscriminatorNet, GeneratorNet
 from .runtime import Ctx, HipOps, Program, View
 
@@ -99,6 +99,13 @@ def build_models(cfg, device):
     return mk_g(), mk_g(), mk_d(), mk_d()
 
 
+def lambda_rule(epoch: int, start_decay: int, total_epochs: int) -> float:
+    """Basic_GAN/src/train.py:27-31: 1 until `start_decay`, then linear decay to 0 at the final epoch."""
+    if epoch < start_decay:
+        return 1.0
+    return max(0.0, 1.0 - float(epoch - start_decay) / float(max(1, total_epochs - start_decay)))
+
+
 SLOTS = {"gan_b": 0, "gan_a": 1, "cyc_a": 2, "cyc_b": 3, "idt_a": 4, "idt_b": 5, "da_real": 6, "da_fake": 7, "db_real": 8, "db_fake": 9}
 
 
@@ -145,6 +152,7 @@ class CycleGANTrainer:
         self.real_a = torch.zeros(B, 3, S, S, dtype=torch.float32, device=self.device)
         self.real_b = torch.zeros_like(self.real_a)
         self.losses = self.ctx.f32(16)
+        self.sched_epoch = 0          # LambdaLR's epoch counter (train.py:54-58): advanced by scheduler_step() at every epoch end
         self._build()
         for net in (self.Gab, self.Gba, self.DA, self.DB):
             net.repack_program().run()
@@ -222,6 +230,48 @@ class CycleGANTrainer:
         self.upd_da = Program("DA-update"); self.upd_da.add(self.opt_DA.step_op(None, gs)); self.upd_da.add(self.DA.repack_program())
         self.upd_db = Program("DB-update"); self.upd_db.add(self.opt_DB.step_op(None, gs)); self.upd_db.add(self.DB.repack_program())
 
+    # ---- epoch end (Basic_GAN/src/train.py:124-137): LambdaLR x 3, then the checkpoint dict
+    def scheduler_step(self) -> float:
+        """sched_G.step(); sched_D_A.step(); sched_D_B.step() (train.py:54-58,125): the scheduler's epoch counter advances and every
+        optimiser's learning rate becomes base_lr * lambda_rule(counter) -- one device float each, the step programs stay as built."""
+        tr, opt = self.cfg["training"], self.cfg["optim"]
+        self.sched_epoch += 1
+        lam = lambda_rule(self.sched_epoch, int(opt.get("lr_decay_after", tr.get("epochs", 1))), int(tr.get("epochs", 1)))
+        for o in (self.opt_G, self.opt_DA, self.opt_DB):
+            o.set_lr(o.base_lr * lam)
+        return lam
+
+    def _module_state(self, opt, prefix=""):
+        return {k[len(prefix):]: v.detach().clone() for k, v in opt.params.items() if k.startswith(prefix)}
+
+    def save_checkpoint(self, path: str, epoch: int):
+        """The dict of train.py:127-137, key for key: epoch, the four state_dicts under the reference's module keys, and the three
+        torch.optim.Adam state_dicts (optim_G numbers list(G_A2B.parameters()) + list(G_B2A.parameters()), train.py:45-48; the param
+        groups carry the `initial_lr` LambdaLR put there and the decayed `lr`).  torch.optim.Adam.load_state_dict accepts them."""
+        ck = {"epoch": int(epoch),
+              "G_A2B": self._module_state(self.opt_G, "ab."), "G_B2A": self._module_state(self.opt_G, "ba."),
+              "D_A": self._module_state(self.opt_DA), "D_B": self._module_state(self.opt_DB),
+              "optim_G": _adam_state_dict(self.opt_G, True), "optim_D_A": _adam_state_dict(self.opt_DA, True),
+              "optim_D_B": _adam_state_dict(self.opt_DB, True)}
+        torch.save(ck, path)
+        return ck
+
+    def load_checkpoint(self, path: str) -> int:
+        """Resumes from a checkpoint in the reference's layout (train.py:127-137; the reference has no resume code of its own: the epoch
+        counter of the three schedulers is taken from `epoch`, as LambdaLR(last_epoch=epoch) would).  Returns the epoch."""
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+        for key, opt, pre in (("G_A2B", self.opt_G, "ab."), ("G_B2A", self.opt_G, "ba."), ("D_A", self.opt_DA, ""), ("D_B", self.opt_DB, "")):
+            for k, v in ck[key].items():
+                opt.params[pre + k].copy_(v)
+        for key, opt in (("optim_G", self.opt_G), ("optim_D_A", self.opt_DA), ("optim_D_B", self.opt_DB)):
+            _load_adam_state_dict(opt, ck[key])
+        self.sched_epoch = int(ck["epoch"])
+        for net in (self.Gab, self.Gba, self.DA, self.DB):
+            net.repack_program().run()
+        from .cut import _notify_weights_changed
+        _notify_weights_changed()
+        return self.sched_epoch
+
     def _allreduce(self, opt):
         if self.world_size > 1:
             import torch.distributed as dist
@@ -229,6 +279,20 @@ class CycleGANTrainer:
 
     def train_iteration(self, real_a: torch.Tensor, real_b: torch.Tensor, sync: bool = True) -> Optional[Dict[str, float]]:
         """One loop iteration; returns {'loss_G','loss_D_A','loss_D_B'} (the values train.py:118-122 shows in its progress bar)."""
+        if self.device.type != "cuda":
+            return self._train_iteration(real_a, real_b, sync)
+        # the programs launch on the stream the op layer was bound to at construction: the copies of this call go there too, ordered
+        # after the caller's current stream (which may have produced the inputs) and before its later work
+        bound, cur = self.ops._ts(), torch.cuda.current_stream(self.device)
+        if bound != cur:
+            bound.wait_stream(cur)
+        with torch.cuda.stream(bound):
+            out = self._train_iteration(real_a, real_b, sync)
+        if bound != cur:
+            cur.wait_stream(bound)
+        return out
+
+    def _train_iteration(self, real_a, real_b, sync):
         self.real_a.copy_(real_a, non_blocking=True)
         self.real_b.copy_(real_b, non_blocking=True)
         self.prog_g_fwd.run()

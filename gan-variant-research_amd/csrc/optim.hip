@@ -16,8 +16,10 @@ namespace {
 constexpr int CHUNK = 16384;  // elements per block
 
 __global__ __launch_bounds__(256) void adam_sumsq_kernel(const gan_adam_tensor* __restrict__ table, const int32_t* __restrict__ chunk_tensor,
-                                                        const int64_t* __restrict__ chunk_off, float grad_scale, float* __restrict__ ws) {
+                                                        const int64_t* __restrict__ chunk_off, float grad_scale, const float* __restrict__ inv_scale_dev,
+                                                        float* __restrict__ ws) {
   const gan_adam_tensor t = table[chunk_tensor[blockIdx.x]];
+  if (inv_scale_dev) grad_scale *= *inv_scale_dev;      // GradScaler.unscale_: the loss scale's reciprocal lives on the device
   float s = 0.f;
   if (t.g) {
     const int64_t off = chunk_off[blockIdx.x];
@@ -36,6 +38,7 @@ __global__ __launch_bounds__(256) void adam_sumsq_kernel(const gan_adam_tensor* 
 __global__ __launch_bounds__(256) void adam_apply_kernel(const gan_adam_tensor* __restrict__ table, const int32_t* __restrict__ chunk_tensor,
                                                         const int64_t* __restrict__ chunk_off, int nchunks, float lr, float beta1, float beta2,
                                                         float eps, float max_norm, float grad_scale, float ema_decay,
+                                                        const float* __restrict__ lr_dev, const float* __restrict__ inv_scale_dev, int skip_nonfinite,
                                                         float* __restrict__ norm_out, const float* __restrict__ ws) {
   __shared__ float sh[16];
   __shared__ float s_bc[2];
@@ -45,7 +48,12 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(const gan_adam_tensor* 
   s = block_sum(s, sh);
   const float total = sqrtf(s);
   const float coef = max_norm > 0.f ? fminf(1.f, max_norm / (total + 1e-6f)) : 1.f;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { norm_out[0] = total; norm_out[1] = coef; }
+  // GradScaler.step: an inf / nan anywhere in the (unscaled) gradients shows in the global norm; the whole step is then skipped
+  const bool found_inf = !(total <= 3.4028234e38f);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { norm_out[0] = total; norm_out[1] = coef; norm_out[2] = found_inf ? 1.f : 0.f; }
+  if (skip_nonfinite && found_inf) return;
+  if (lr_dev) lr = *lr_dev;                             // LambdaLR: the host rewrites one device float, the prebuilt launch stays
+  if (inv_scale_dev) grad_scale *= *inv_scale_dev;
   const gan_adam_tensor t = table[chunk_tensor[blockIdx.x]];
   if (!t.g) return;
   if (threadIdx.x == 0) {
@@ -73,9 +81,21 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(const gan_adam_tensor* 
   }
 }
 
-__global__ void adam_bump_kernel(const gan_adam_tensor* __restrict__ table, int ntensors) {
+__global__ void adam_bump_kernel(const gan_adam_tensor* __restrict__ table, int ntensors, int skip_nonfinite, const float* __restrict__ norm_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (skip_nonfinite && norm_out[2] != 0.f) return;     // a skipped step does not count (torch: optimizer.step is not called)
   if (i < ntensors && table[i].g) *table[i].step += 1;
+}
+
+// torch.amp.GradScaler.update (amp_utils.py:22,41 call it after every step): backoff on an overflow, growth after `interval` clean steps
+__global__ void scaler_update_kernel(float* scale, float* inv_scale, int32_t* tracker, const float* found_inf, float growth, float backoff, int interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float sc = *scale;
+  if (*found_inf != 0.f) { sc *= backoff; *tracker = 0; }
+  else if (*tracker + 1 >= interval) { sc *= growth; *tracker = 0; }
+  else *tracker += 1;
+  *scale = sc;
+  *inv_scale = 1.f / sc;
 }
 
 }  // namespace
@@ -83,13 +103,23 @@ __global__ void adam_bump_kernel(const gan_adam_tensor* __restrict__ table, int 
 // ws: fp32 >= nchunks floats.  Chunks are CHUNK=16384-element slices: chunk_tensor[k], chunk_off[k].
 extern "C" int gan_adam_step(const gan_adam_tensor* table, int ntensors, const int32_t* chunk_tensor, const int64_t* chunk_off, int nchunks,
                              float lr, float beta1, float beta2, float eps, float max_norm, float grad_scale, float ema_decay,
-                             float* norm_out, float* ws, void* stream) {
+                             const float* lr_dev, const float* inv_scale_dev, int skip_nonfinite, float* norm_out, float* ws, void* stream) {
   GAN_CHECK(table && chunk_tensor && chunk_off && norm_out && ws && ntensors > 0 && nchunks > 0, "adam: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, table, chunk_tensor, chunk_off, grad_scale, ws);
+  hipLaunchKernelGGL(adam_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, table, chunk_tensor, chunk_off, grad_scale, inv_scale_dev, ws);
   hipLaunchKernelGGL(adam_apply_kernel, dim3(nchunks), dim3(256), 0, s, table, chunk_tensor, chunk_off, nchunks, lr, beta1, beta2, eps, max_norm,
-                     grad_scale, ema_decay, norm_out, ws);
-  hipLaunchKernelGGL(adam_bump_kernel, dim3((ntensors + 63) / 64), dim3(64), 0, s, table, ntensors);
+                     grad_scale, ema_decay, lr_dev, inv_scale_dev, skip_nonfinite, norm_out, ws);
+  hipLaunchKernelGGL(adam_bump_kernel, dim3((ntensors + 63) / 64), dim3(64), 0, s, table, ntensors, skip_nonfinite, norm_out);
+  GAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gan_scaler_update(float* scale, float* inv_scale, int32_t* growth_tracker, const float* found_inf, float growth_factor,
+                                 float backoff_factor, int growth_interval, void* stream) {
+  GAN_CHECK(scale && inv_scale && growth_tracker && found_inf && growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval > 0,
+            "scaler_update: bad arguments");
+  hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scale, inv_scale, growth_tracker, found_inf, growth_factor, backoff_factor,
+                     growth_interval);
   GAN_LAUNCH_CHECK();
   return 0;
 }

@@ -266,6 +266,12 @@ int gan_wgrad_patch_launch(const gan_wgrad_desc* d, hipStream_t s) {
   a.x_Hp = d->x_Hp; a.x_Wp = d->x_Wp; a.x_y0 = d->x_y0; a.x_x0 = d->x_x0;
   a.g_Hp = d->g_Hp; a.g_Wp = d->g_Wp; a.g_C = d->g_C; a.g_y0 = d->g_y0; a.g_x0 = d->g_x0;
   a.NBLK = d->N / NB; a.CBLK = d->Cx / CB;
+  // the planner's split count must be the one gan_wgrad_patch_splits answered (the kernels index partial slabs and images by it), and the
+  // row-ring variant walks ONE image per split
+  const bool ring = a.nrows * a.pitch > RX;
+  GAN_CHECK(spi_want > 0 ? d->nsplit == d->B * spi_want : d->nsplit * -spi_want == d->B, "wgrad_patch: nsplit=%d is not what gan_wgrad_patch_splits implies (%d)",
+            d->nsplit, spi_want);
+  GAN_CHECK(!(ring && a.ipb > 1), "wgrad_patch: the row-ring variant (128-pixel-wide maps) takes one image per split");
   static std::atomic<uint64_t> attr_devs{0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return gan_set_error(-2, "wgrad_patch: hipGetDevice failed");

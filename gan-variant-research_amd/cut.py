@@ -319,9 +319,18 @@ class FusedAdam:
         self.nchunks = len(ct)
         self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=dev)
         self.chunk_off = torch.tensor(co, dtype=torch.int64, device=dev)
-        self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.norm_out = torch.zeros(4, dtype=torch.float32, device=dev)
         self.ws = torch.zeros(self.nchunks + 16, dtype=torch.float32, device=dev)
         self._tables = {}
+        # the learning rate lives in one device float that the prebuilt launches read (gan_adam_step lr_dev): a scheduler
+        # (Basic_GAN/src/train.py:54-58,125: LambdaLR) rewrites it between epochs without rebuilding any program
+        self.base_lr = float(lr)
+        self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
+
+    def set_lr(self, lr: float):
+        """What LambdaLR.step() does to param_groups[0]['lr'] (train.py:125): takes effect with the next step."""
+        self.lr = float(lr)
+        self.lr_dev.fill_(float(lr))
 
     def table(self, skip: Sequence[str] = ()) -> torch.Tensor:
         key = tuple(sorted(skip))
@@ -338,10 +347,10 @@ class FusedAdam:
     def step_op(self, max_norm: Optional[float], grad_scale: float = 1.0, skip: Sequence[str] = ()):
         return self.ctx.ops.adam_step(self.table(skip), len(self.names), self.chunk_tensor, self.chunk_off, self.nchunks, self.lr,
                                       self.betas[0], self.betas[1], self.eps, max_norm if max_norm is not None else 0.0, grad_scale,
-                                      self.ema_decay if self.ema_decay is not None else 0.0, self.norm_out, self.ws)
+                                      self.ema_decay if self.ema_decay is not None else 0.0, self.norm_out, self.ws, lr_dev=self.lr_dev)
 
 
-def _adam_state_dict(opt: "FusedAdam") -> dict:
+def _adam_state_dict(opt: "FusedAdam", with_initial_lr: bool = False) -> dict:
     """torch.optim.Adam.state_dict() layout (what utils/io_ckpt.py:70-71 stores), parameters numbered in state_dict order."""
     steps = opt.steps.cpu()
     state = {}
@@ -352,6 +361,8 @@ def _adam_state_dict(opt: "FusedAdam") -> dict:
                     "exp_avg_sq": opt.flat_v[o:o + sz].view(shp).clone()}
     group = {"lr": opt.lr, "betas": tuple(opt.betas), "eps": opt.eps, "weight_decay": 0.0, "amsgrad": False, "maximize": False, "foreach": None,
              "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(opt.names)))}
+    if with_initial_lr:      # torch.optim.lr_scheduler.LambdaLR adds it to every param group it schedules (Basic_GAN/src/train.py:54-58)
+        group["initial_lr"] = opt.base_lr
     return {"state": state, "param_groups": [group]}
 
 
@@ -367,8 +378,12 @@ def _load_adam_state_dict(opt: "FusedAdam", sd: dict):
         steps[i] = int(float(st["step"]))
     opt.steps.copy_(steps)
     g = sd["param_groups"][0]
-    if (g["lr"], tuple(g["betas"]), g["eps"]) != (opt.lr, tuple(opt.betas), opt.eps):
+    if (tuple(g["betas"]), g["eps"]) != (tuple(opt.betas), opt.eps):
         raise ValueError("checkpoint optimiser hyper-parameters differ from the trainer's config (they are baked into its programs)")
+    if g["lr"] != opt.lr:       # a scheduler had moved it (Basic_GAN's LambdaLR): the device scalar follows the checkpoint
+        opt.set_lr(g["lr"])
+    if "initial_lr" in g:
+        opt.base_lr = float(g["initial_lr"])
 
 
 def get_optimizer_config(opt_config: dict) -> dict:
@@ -815,8 +830,16 @@ class CutTrainer:
             return self._train_step(step, photos, monets, rnd, sync)
         # the programs launch on the stream the op layer was bound to at construction; the torch-side copies, fills and events of a
         # step must be queued on that same stream whatever the caller has made current
-        with torch.cuda.stream(self.ops._ts()):
-            return self._train_step(step, photos, monets, rnd, sync)
+        # ... and ordered against the caller's: the inputs may have been produced on another stream (a prefetch stream, a transform under
+        # `with torch.cuda.stream(s)`), and the caller's later work may read this step's results
+        bound, cur = self.ops._ts(), torch.cuda.current_stream(self.device)
+        if bound != cur:
+            bound.wait_stream(cur)
+        with torch.cuda.stream(bound):
+            out = self._train_step(step, photos, monets, rnd, sync)
+        if bound != cur:
+            cur.wait_stream(bound)
+        return out
 
     def _train_step(self, step, photos, monets, rnd, sync):
         cfg = self.config

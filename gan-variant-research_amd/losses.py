@@ -22,6 +22,7 @@ _PLANS: Dict[tuple, object] = {}
 
 
 def _plan(key, make):
+    key = key + (torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0,)      # see ops_library._stream_key
     p = _PLANS.get(key)
     if p is None:
         p = _PLANS[key] = make()
@@ -173,21 +174,6 @@ class _NcePlan(_Plan):
         self.fwd.add(ops.view_to_nchw(gv, C, self.g))
 
 
-class _NceFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, src, tgt, ids, temperature):
-        P = int(ids.numel())
-        p = _plan(("nce", tuple(tgt.shape), tgt.device, P, float(temperature)), lambda: _NcePlan(tuple(tgt.shape), tgt.device, P, temperature))
-        p.src.copy_(src); p.tgt.copy_(tgt); p.ids.copy_(ids)
-        p.fwd.run()
-        ctx.save_for_backward(p.g.clone())
-        return p.loss.clone().reshape(())
-
-    @staticmethod
-    def backward(ctx, g):
-        return None, ctx.saved_tensors[0] * g, None, None
-
-
 class PatchNCELoss(nn.Module):
     """patchnce_cut.py:7-110.  One patch-id draw per layer (`torch.randint(0, H*W, (num_patches,), device=...)`, :63) shared by
     the batch and by source / target; the source features carry no gradient (compute_patchnce_loss detaches them)."""
@@ -200,7 +186,9 @@ class PatchNCELoss(nn.Module):
         B, C, H, W = tgt_feat.shape
         if patch_ids is None:
             patch_ids = torch.randint(0, H * W, (self.num_patches,), device=tgt_feat.device)
-        return _NceFn.apply(src_feat.detach().float().contiguous(), tgt_feat.float().contiguous(), patch_ids.to(torch.int32), self.temperature)
+        from . import ops_library  # noqa: F401  (registers torch.ops.mi355x_gan.*)
+        loss, _ = torch.ops.mi355x_gan.patchnce_fwd(src_feat.detach(), tgt_feat, patch_ids.to(torch.int32), self.temperature)
+        return loss
 
     def forward(self, src_feats, tgt_feats, patch_ids: Optional[List[torch.Tensor]] = None):
         total = 0.0
@@ -242,24 +230,6 @@ class _AugPlan(_Plan):
         self.bwd.add(ops.view_to_nchw(vgx, C, self.gx))
 
 
-class _AugFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, prm):
-        p = _plan(("aug", tuple(x.shape), x.device), lambda: _AugPlan(tuple(x.shape), x.device))
-        p.x.copy_(x); p.prm.copy_(prm)
-        p.fwd.run()
-        ctx.plan = p
-        ctx.save_for_backward(prm)
-        return p.y.clone()
-
-    @staticmethod
-    def backward(ctx, g):
-        p = ctx.plan
-        p.gy.copy_(g); p.prm.copy_(ctx.saved_tensors[0])
-        p.bwd.run()
-        return p.gx.clone(), None
-
-
 class DiffAugment(_DiffAugmentSampler):
     """training/diffaugment.py:76-106 as a differentiable callable: brightness, saturation, contrast, translation and cutout in
     one gather pass each way.  `generator` (optional) makes the per-sample draws reproducible; `last_draws` keeps them."""
@@ -268,4 +238,5 @@ class DiffAugment(_DiffAugmentSampler):
         B, C, H, W = x.shape
         self.last_draws = draws if draws is not None else self.sample(B, H, W, generator)
         prm = self.to_params(self.last_draws, B, H, W).to(x.device)
-        return _AugFn.apply(x.float().contiguous(), prm)
+        from . import ops_library  # noqa: F401
+        return torch.ops.mi355x_gan.diffaugment_fwd(x, prm)

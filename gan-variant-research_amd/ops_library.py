@@ -42,7 +42,15 @@ def set_compute_dtype(dtype: int):
     _COMPUTE_DTYPE[0] = dtype
 
 
+def _stream_key() -> int:
+    """A plan's launches are bound to the HIP stream that was current when it was built (raw handle in the prebuilt calls) while its
+    staging copies run on whatever stream is current at the call: the current stream is therefore part of every plan key, so a caller
+    working on another stream (a prefetch stream, `with torch.cuda.stream(s)`) gets a plan of its own instead of an unordered pair."""
+    return torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0
+
+
 def _plan(key, make):
+    key = key + (_stream_key(),)
     p = _PLANS.get(key)
     if p is None:
         p = _PLANS[key] = make()
@@ -139,7 +147,12 @@ _LIB.define("replication_pad2d(Tensor x, int pad) -> Tensor")
 _LIB.define("replication_pad2d_bwd(Tensor gy, int pad) -> Tensor")
 _LIB.define("act_bwd(Tensor y, Tensor gy, int act) -> Tensor")
 _LIB.define("fused_clip_adam_ema_(Tensor(a!)[] params, Tensor[] grads, Tensor(b!)[] m, Tensor(c!)[] v, Tensor(d!)[] ema, Tensor(e!) steps, float lr, float b1, "
-            "float b2, float eps, float max_norm, float grad_scale, float ema_decay) -> Tensor")
+            "float b2, float eps, float max_norm, float grad_scale, float ema_decay, Tensor? inv_scale=None, bool skip_nonfinite=False) -> (Tensor, Tensor)")
+_LIB.define("patchnce_fwd(Tensor src_feat, Tensor tgt_feat, Tensor ids, float temperature) -> (Tensor, Tensor)")
+_LIB.define("patchnce_bwd(Tensor saved, Tensor grad_loss) -> Tensor")
+_LIB.define("diffaugment_fwd(Tensor x, Tensor params) -> Tensor")
+_LIB.define("diffaugment_bwd(Tensor gy, Tensor params) -> Tensor")
+_LIB.define("allreduce_bucket_(Tensor(a!) flat, str group) -> Tensor(a!)")
 
 
 def _conv_fwd(x, w, b, stride, pad, pad_mode, act, transposed=False):
@@ -303,12 +316,54 @@ _LIB.impl("act_bwd", lambda y, gy, act: _act_bwd(_f(y), _f(gy), act), _IMPL)
 
 
 # ---- fused clip_grad_norm_ + Adam + EMA.update (amp_utils.py:29-41, sched_optim.py:5-27, io_ckpt.py:23-29)
-def _fused_adam(params, grads, m, v, ema, steps, lr, b1, b2, eps, max_norm, grad_scale, ema_decay):
+def _fused_adam(params, grads, m, v, ema, steps, lr, b1, b2, eps, max_norm, grad_scale, ema_decay, inv_scale=None, skip_nonfinite=False):
     from .training import fused_adam_launch
-    return fused_adam_launch(list(params), list(grads), list(m), list(v), list(ema), steps, lr, b1, b2, eps, max_norm, grad_scale, ema_decay)
+    return fused_adam_launch(list(params), list(grads), list(m), list(v), list(ema), steps, lr, b1, b2, eps, max_norm, grad_scale, ema_decay,
+                             inv_scale, skip_nonfinite)
 
 
 _LIB.impl("fused_clip_adam_ema_", _fused_adam, _IMPL)
+
+
+# ---- PatchNCE (patchnce_cut.py:42-110) and DiffAugment (diffaugment.py:94-106): value and input gradient come out of one pass each,
+#      so the forward op hands the gradient for a unit upstream gradient to its backward op as `saved`
+def _nce_fwd(src, tgt, ids, temperature):
+    from . import losses as LS
+    P = int(ids.numel())
+    p = LS._plan(("nce", tuple(tgt.shape), tgt.device, P, float(temperature)), lambda: LS._NcePlan(tuple(tgt.shape), tgt.device, P, temperature))
+    p.src.copy_(src); p.tgt.copy_(tgt); p.ids.copy_(ids)
+    p.fwd.run()
+    return p.loss.clone().reshape(()), p.g.clone()
+
+
+def _aug_run(x, prm, backward):
+    from . import losses as LS
+    p = LS._plan(("aug", tuple(x.shape), x.device), lambda: LS._AugPlan(tuple(x.shape), x.device))
+    p.prm.copy_(prm)
+    if backward:
+        p.gy.copy_(x)
+        p.bwd.run()
+        return p.gx.clone()
+    p.x.copy_(x)
+    p.fwd.run()
+    return p.y.clone()
+
+
+def _allreduce_bucket(flat, group):
+    """The gradient all-reduce of one flat bucket (SUM over RCCL on a GPU, gloo on the CPU tests): `group` names a process group
+    ('' = the default one); without an initialised group the single-process trainers call it as a no-op."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        pg = dist.distributed_c10d._resolve_process_group(group) if group else None
+        dist.all_reduce(flat, group=pg)
+    return flat
+
+
+_LIB.impl("patchnce_fwd", lambda src, tgt, ids, temperature: _nce_fwd(_f(src), _f(tgt), ids.to(torch.int32), temperature), _IMPL)
+_LIB.impl("patchnce_bwd", lambda saved, g: saved * g, _IMPL)
+_LIB.impl("diffaugment_fwd", lambda x, prm: _aug_run(_f(x), prm, False), _IMPL)
+_LIB.impl("diffaugment_bwd", lambda gy, prm: _aug_run(_f(gy), prm, True), _IMPL)
+_LIB.impl("allreduce_bucket_", _allreduce_bucket, _IMPL)
 
 
 # ------------------------------------------------------------------------------------------------ autograd formulas
@@ -366,6 +421,22 @@ torch.library.register_autograd("mi355x_gan::reflection_pad2d", lambda ctx, g: (
                                 setup_context=lambda ctx, inputs, output: setattr(ctx, "pad", inputs[1]))
 
 
+def _nce_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1])
+
+
+def _nce_backward(ctx, g_loss, g_saved):
+    # the source features carry no gradient (patchnce_cut.py:138-142 computes them under no_grad), nor do the ids
+    return None, torch.ops.mi355x_gan.patchnce_bwd(ctx.saved_tensors[0], g_loss), None, None
+
+
+def _aug_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[1])
+
+
+torch.library.register_autograd("mi355x_gan::patchnce_fwd", _nce_backward, setup_context=_nce_setup)
+torch.library.register_autograd("mi355x_gan::diffaugment_fwd", lambda ctx, g: (torch.ops.mi355x_gan.diffaugment_bwd(g.contiguous(), ctx.saved_tensors[0]), None),
+                                setup_context=_aug_setup)
 torch.library.register_autograd("mi355x_gan::replication_pad2d", lambda ctx, g: (torch.ops.mi355x_gan.replication_pad2d_bwd(g.contiguous(), ctx.pad), None),
                                 setup_context=lambda ctx, inputs, output: setattr(ctx, "pad", inputs[1]))
 

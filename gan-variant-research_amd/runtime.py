@@ -565,10 +565,19 @@ class HipOps:
                           self._p(ws), self._s())
 
     # ---- optimiser
-    def adam_step(self, table, ntensors, chunk_tensor, chunk_off, nchunks, lr, b1, b2, eps, max_norm, grad_scale, ema_decay, norm_out, ws) -> Op:
+    def adam_step(self, table, ntensors, chunk_tensor, chunk_off, nchunks, lr, b1, b2, eps, max_norm, grad_scale, ema_decay, norm_out, ws,
+                  lr_dev=None, inv_scale=None, skip_nonfinite=False) -> Op:
+        """lr_dev: device float that holds the learning rate (a scheduler rewrites it; `lr` is then ignored); inv_scale / skip_nonfinite:
+        GradScaler semantics (gradients x *inv_scale; a non-finite norm skips the step); norm_out: [3] (norm, clip coefficient, found_inf)."""
+        assert norm_out.numel() >= 3
         return self._call("gan_adam_step", self._p(table), ntensors, self._p(chunk_tensor), self._p(chunk_off), nchunks, C.c_float(lr),
                           C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(max_norm), C.c_float(grad_scale), C.c_float(ema_decay),
-                          self._p(norm_out), self._p(ws), self._s())
+                          self._p(lr_dev), self._p(inv_scale), int(skip_nonfinite), self._p(norm_out), self._p(ws), self._s())
+
+    def scaler_update(self, scale, inv_scale, tracker, found_inf, growth=2.0, backoff=0.5, interval=2000) -> Op:
+        assert tracker.dtype == torch.int32
+        return self._call("gan_scaler_update", self._p(scale), self._p(inv_scale), self._p(tracker), self._p(found_inf), C.c_float(growth),
+                          C.c_float(backoff), int(interval), self._s())
 
     def make_adam_table(self, entries: Sequence[dict]) -> torch.Tensor:
         """entries: dicts with tensors p, g (or None), m, v, ema (or None), step (int32 tensor of 1).  -> device uint8 table."""

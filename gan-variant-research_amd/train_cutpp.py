@@ -97,7 +97,7 @@ class LossLog:
 
     def __init__(self, log_dir: Path):
         log_dir.mkdir(parents=True, exist_ok=True)
-        self.csv = open(log_dir / "training_losses.csv", "a")
+        self.csv = open(log_dir / "losses_history.csv", "a")      # the file name of utils/loss_tracker.py:17
         if self.csv.tell() == 0:
             self.csv.write("step,d_loss,g_loss\n")
         self.txt = log_dir / "train_log.txt"
@@ -129,9 +129,14 @@ def main(argv=None, ops=None, device: Optional[str] = None) -> dict:
     B, S = int(config["batch_size"]), int(config["image_size"])
     build = config.get("mi355x", {}) or {}
     photos_paths, monet_paths = _list_images(config["data"]["photos_dir"]), _list_images(config["data"]["monet_dir"])
-    synthetic = args.synthetic or build.get("synthetic", False) or len(photos_paths) < B or len(monet_paths) < B
+    synthetic = bool(args.synthetic or build.get("synthetic", False))
+    if not synthetic:      # like the reference, a wrong data path is an error -- never a silent run on noise that still writes ckpt_*.pt
+        for name, paths in (("photos_dir", photos_paths), ("monet_dir", monet_paths)):
+            if len(paths) < B:
+                raise FileNotFoundError(f"data.{name} = {config['data'][name]!r} holds {len(paths)} images (< batch_size {B}); "
+                                        "pass --synthetic (or mi355x.synthetic: true) to train on uniform-noise batches instead")
     if synthetic:
-        print("[train_cutpp] image folders not found (or --synthetic): uniform-noise batches stand in for the data loaders")
+        print("[train_cutpp] --synthetic: uniform-noise batches stand in for the data loaders")
         photos_it, monet_it = synthetic_batches(B, S, device, 1234), synthetic_batches(B, S, device, 4321)
         steps_per_epoch = 7038 // B          # the reference's photo count (train_gan_cutpp.yaml: 70 epochs x 7038 // 12 steps)
     else:

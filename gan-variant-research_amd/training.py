@@ -55,7 +55,7 @@ class HipAdam(torch.optim.Optimizer):
 
     def _plan(self, gi, group, live):
         """Prebuilt launch for one param group and one pattern of present gradients (ops hold raw pointers)."""
-        key = (gi, live, group["lr"], group["betas"], group["eps"])
+        key = (gi, live, group["lr"], group["betas"], group["eps"], torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
         pl = self._plans.get(key)
         if pl is None:
             ps = group["params"]
@@ -68,7 +68,7 @@ class HipAdam(torch.optim.Optimizer):
                              "v": st["exp_avg_sq"].view(-1), "ema": self._ema[id(p)].view(-1) if id(p) in self._ema else None, "step": st["step"]})
                 for off in range(0, p.numel(), ADAM_CHUNK):
                     ct.append(i); co.append(off)
-            pl = {"ctx": ctx, "norm": torch.zeros(2, dtype=torch.float32, device=dev),
+            pl = {"ctx": ctx, "norm": torch.zeros(4, dtype=torch.float32, device=dev),
                   "ct": torch.tensor(ct, dtype=torch.int32, device=dev), "co": torch.tensor(co, dtype=torch.int64, device=dev),
                   "ws": torch.zeros(len(ct) + 16, dtype=torch.float32, device=dev), "ops": {}}
             pl["table"] = ctx.ops.make_adam_table(ents)
@@ -125,32 +125,48 @@ class HipAdam(torch.optim.Optimizer):
 _FUSED_PLANS = {}
 
 
-def fused_adam_launch(params, grads, m, v, ema, steps, lr, b1, b2, eps, max_norm, grad_scale, ema_decay):
+def fused_adam_launch(params, grads, m, v, ema, steps, lr, b1, b2, eps, max_norm, grad_scale, ema_decay, inv_scale=None, skip_nonfinite=False):
     """Body of torch.ops.mi355x_gan.fused_clip_adam_ema_: clip_grad_norm_(max_norm; 0 = off) on grads * grad_scale, one Adam
     step of every tensor (per-tensor step counters `steps`, int32 [n], incremented on the device) and, if `ema` is non-empty,
-    shadow <- decay * shadow + (1 - decay) * p, in three launches regardless of the tensor count.  Returns the total gradient norm."""
+    shadow <- decay * shadow + (1 - decay) * p, in three launches regardless of the tensor count.  inv_scale (device float) and
+    skip_nonfinite: GradScaler's unscale_ / step.  Returns (total gradient norm, found_inf).
+    The prebuilt launch is keyed on the STATE tensors only (params, m, v, ema, steps): gradients are fresh tensors every step under
+    zero_grad(set_to_none=True), so they are copied into staging buffers the plan owns (one multi-tensor copy) -- a plan per gradient
+    address would grow without bound and pin every old gradient."""
     n = len(params)
     assert n and len(grads) == n and len(m) == n and len(v) == n and len(ema) in (0, n) and steps.dtype == torch.int32 and steps.numel() == n
-    key = tuple(t.data_ptr() for grp in (params, grads, m, v, ema) for t in grp) + (steps.data_ptr(),)
+    key = tuple((t.data_ptr(), t.numel()) for grp in (params, m, v, ema) for t in grp) + (steps.data_ptr(), inv_scale.data_ptr() if inv_scale is not None else 0,
+                                                                                         torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
     pl = _FUSED_PLANS.get(key)
     if pl is None:
         dev = params[0].device
         ctx = AG._new_ctx(dev, F32)
-        ents, ct, co = [], [], []
+        ents, ct, co, gbuf = [], [], [], []
         for i in range(n):
-            for t in (params[i], grads[i], m[i], v[i]) + ((ema[i],) if ema else ()):
+            for t in (params[i], m[i], v[i]) + ((ema[i],) if ema else ()):
                 assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == params[i].numel()
-            ents.append({"p": params[i].view(-1), "g": grads[i].view(-1), "m": m[i].view(-1), "v": v[i].view(-1),
+            gbuf.append(torch.zeros(params[i].numel(), dtype=torch.float32, device=dev))
+            ents.append({"p": params[i].view(-1), "g": gbuf[i], "m": m[i].view(-1), "v": v[i].view(-1),
                          "ema": ema[i].view(-1) if ema else None, "step": steps[i:i + 1]})
             for off in range(0, params[i].numel(), ADAM_CHUNK):
                 ct.append(i); co.append(off)
-        pl = _FUSED_PLANS[key] = {"ctx": ctx, "norm": torch.zeros(2, dtype=torch.float32, device=dev), "table": ctx.ops.make_adam_table(ents),
+        if len(_FUSED_PLANS) >= 8:      # a handful of optimisers per process; anything beyond that is a caller churning its state tensors
+            _FUSED_PLANS.pop(next(iter(_FUSED_PLANS)))
+        pl = _FUSED_PLANS[key] = {"ctx": ctx, "norm": torch.zeros(4, dtype=torch.float32, device=dev), "table": ctx.ops.make_adam_table(ents),
                                   "ct": torch.tensor(ct, dtype=torch.int32, device=dev), "co": torch.tensor(co, dtype=torch.int64, device=dev),
-                                  "ws": torch.zeros(len(ct) + 16, dtype=torch.float32, device=dev), "keep": (params, grads, m, v, ema, steps)}
-    pl["ctx"].ops.adam_step(pl["table"], n, pl["ct"], pl["co"], len(pl["ct"]), lr, b1, b2, eps, max_norm, grad_scale, ema_decay if ema else 0.0,
-                            pl["norm"], pl["ws"])()
+                                  "ws": torch.zeros(len(ct) + 16, dtype=torch.float32, device=dev), "gbuf": gbuf,
+                                  "keep": (params, m, v, ema, steps, inv_scale), "ops": {}}
+    for g, p in zip(grads, params):
+        assert g.dtype == torch.float32 and g.numel() == p.numel()
+    torch._foreach_copy_(pl["gbuf"], [g.reshape(-1) for g in grads])
+    hk = (lr, b1, b2, eps, max_norm, grad_scale, ema_decay if ema else 0.0, bool(skip_nonfinite))
+    op = pl["ops"].get(hk)
+    if op is None:
+        op = pl["ops"][hk] = pl["ctx"].ops.adam_step(pl["table"], n, pl["ct"], pl["co"], len(pl["ct"]), lr, b1, b2, eps, max_norm, grad_scale,
+                                                      ema_decay if ema else 0.0, pl["norm"], pl["ws"], inv_scale=inv_scale, skip_nonfinite=skip_nonfinite)
+    op()
     AG.notify_weights_changed()
-    return pl["norm"][:1].clone()
+    return pl["norm"][:1].clone(), pl["norm"][2:3].clone()
 
 
 def get_optimizer(model, opt_config: dict):
@@ -206,12 +222,10 @@ class AMPContext(_AMPBase):
         loss.backward()
 
     def step_optimizer(self, optimizer, max_grad_norm=None):
-        if isinstance(optimizer, HipAdam):
-            optimizer.step(max_grad_norm=max_grad_norm)            # clipping is fused into the optimiser launch
-            return
-        if max_grad_norm is not None:
-            torch.nn.utils.clip_grad_norm_([p for g in optimizer.param_groups for p in g["params"] if p.grad is not None], max_grad_norm)
-        optimizer.step()
+        if not isinstance(optimizer, HipAdam):      # no ATen fallback on this path: get_optimizer() hands out the fused optimiser
+            raise TypeError(f"AMPContext.step_optimizer drives HipAdam (training.get_optimizer); got {type(optimizer).__name__}, whose "
+                            "clip_grad_norm_ + step would run on ATen")
+        optimizer.step(max_grad_norm=max_grad_norm)            # clipping is fused into the optimiser launch
 
 
 class EMA:

@@ -320,11 +320,20 @@ typedef struct gan_adam_tensor {
   int32_t* step;                                               /* device per-tensor step counter (incremented) */
   int64_t _pad;
 } gan_adam_tensor;
-/* norm_out: device fp32 [2] = (total L2 norm before clipping, clip coefficient).  max_norm <= 0: no clipping.
- * grad_scale multiplies every gradient first (1/world_size after a sum all-reduce). */
+/* norm_out: device fp32 [3] = (total L2 norm before clipping, clip coefficient, found_inf).  max_norm <= 0: no clipping.
+ * grad_scale multiplies every gradient first (1/world_size after a sum all-reduce).
+ * lr_dev (optional device float): the learning rate is read from it instead of `lr` -- a scheduler (Basic_GAN/src/train.py:27-31,54-58,125:
+ *   LambdaLR with lambda_rule) rewrites one device float and the prebuilt launch stays valid.
+ * inv_scale_dev (optional device float) and skip_nonfinite: torch.amp.GradScaler's unscale_ / step (amp_utils.py:29-41): gradients are
+ *   multiplied by *inv_scale_dev, and with skip_nonfinite a non-finite total norm skips the update AND the step counters; found_inf is
+ *   written to norm_out[2] either way (gan_scaler_update consumes it). */
 int gan_adam_step(const gan_adam_tensor* table, int ntensors, const int32_t* chunk_tensor, const int64_t* chunk_off,
                   int nchunks, float lr, float beta1, float beta2, float eps, float max_norm, float grad_scale,
-                  float ema_decay, float* norm_out, float* ws, void* stream);
+                  float ema_decay, const float* lr_dev, const float* inv_scale_dev, int skip_nonfinite, float* norm_out, float* ws, void* stream);
+/* torch.amp.GradScaler.update on the device (amp_utils.py:22,41): scale *= backoff_factor after an overflow (found_inf != 0, e.g.
+ * norm_out + 2 of gan_adam_step), *= growth_factor after growth_interval clean steps; inv_scale = 1 / scale; no host synchronisation. */
+int gan_scaler_update(float* scale, float* inv_scale, int32_t* growth_tracker, const float* found_inf, float growth_factor,
+                      float backoff_factor, int growth_interval, void* stream);
 
 /* small helpers */
 int gan_fill_f32(float* p, int64_t n, float v, void* stream);

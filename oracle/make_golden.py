@@ -214,6 +214,30 @@ def gen_basic():
     np.savez_compressed(os.path.join(OUT, "basic.npz"), **_np(out))
 
 
+def gen_basic_sched():
+    """Basic_GAN/src/train.py:27-31,54-58,125: lambda_rule itself and the learning rates LambdaLR hands an Adam optimiser epoch by epoch
+    (the reference's own function and torch's scheduler; numbers only)."""
+    from src.train import lambda_rule  # Basic_GAN/src
+    from torch.optim import Adam
+    from torch.optim.lr_scheduler import LambdaLR
+
+    out = {}
+    for start, total in ((100, 200), (3, 6), (0, 5), (5, 5), (7, 4)):
+        out[f"lambda.{start}.{total}"] = torch.tensor([lambda_rule(e, start, total) for e in range(total + 3)], dtype=torch.float64)
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = Adam([p], lr=2e-4, betas=(0.5, 0.999))
+    sched = LambdaLR(opt, lambda e: lambda_rule(e, 3, 6))
+    lrs = [opt.param_groups[0]["lr"]]
+    for _ in range(7):
+        p.grad = torch.ones(3)
+        opt.step()
+        sched.step()
+        lrs.append(opt.param_groups[0]["lr"])
+    out["lr_seq.3.6"] = torch.tensor(lrs, dtype=torch.float64)
+    out["initial_lr"] = torch.tensor(opt.state_dict()["param_groups"][0]["initial_lr"], dtype=torch.float64)
+    np.savez_compressed(os.path.join(OUT, "basic_sched.npz"), **_np(out))
+
+
 def gen_optional(tc):
     """Architecture switches that are off in train_gan_cutpp.yaml but are the constructor defaults: the multiscale
     discriminator (num_scales=3, AvgPool2d(3,2,1,count_include_pad=False) between scales) and spectral normalisation
@@ -435,6 +459,10 @@ def main():
         print("input_pipeline.npz", os.path.getsize(os.path.join(OUT, "input_pipeline.npz")))
         return
     tc = _import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "sched":
+        gen_basic_sched()
+        print("basic_sched.npz", os.path.getsize(os.path.join(OUT, "basic_sched.npz")))
+        return
     gen_input()
     if len(sys.argv) > 1 and sys.argv[1] == "variants":
         gen_variants(tc)
@@ -451,6 +479,7 @@ def main():
     gen_optim(tc)
     gen_steps(tc)
     gen_basic()
+    gen_basic_sched()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

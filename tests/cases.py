@@ -276,3 +276,62 @@ def run_conv_fp8(ctx, B=2, C_=256, H=16, seed=0, with_stats=False, info=None):
         assert float((gotd[bi] - xr.grad[bi]).pow(2).mean().sqrt()) < 0.06 * r, (bi, float((gotd[bi] - xr.grad[bi]).pow(2).mean().sqrt()), r)
         assert float((gotd[bi] - xr.grad[bi]).abs().max()) < 0.3 * r
     return got, gotd
+
+
+def run_basic_checkpoint_case(device, make_ops, tmp_path, S=32, B=2):
+    """f-1 for the CycleGAN trainer (Basic_GAN/src/train.py:27-31,54-58,124-137): two iterations, epoch end (scheduler step + checkpoint in
+    the reference's dict layout), a third iteration -- against a fresh trainer that loads the checkpoint and runs the third iteration:
+    identical losses and parameters.  The checkpoint must load into the reference-named modules and into torch.optim.Adam."""
+    from gan_variant_research_amd import basic as BG
+    cfg = basic_config()
+    cfg["training"].update({"epochs": 4, "save_every": 1})
+    cfg["optim"]["lr_decay_after"] = 1
+    g = torch.Generator().manual_seed(77)
+    a = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(device)
+    b = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(device)
+
+    def fresh():
+        torch.manual_seed(0)
+        mods = BG.build_models(cfg, "cpu")
+        return BG.CycleGANTrainer(*[m.to(device) for m in mods], cfg, B, S, device=device, amp=False, ops=make_ops()), mods
+    tr, mods = fresh()
+    for _ in range(2):
+        tr.train_iteration(a, b)
+    assert tr.scheduler_step() == 1.0                         # epoch 1 < lr_decay_after + ... : lambda_rule(1, 1, 4) = 1
+    lam = tr.scheduler_step()                                 # lambda_rule(2, 1, 4) = 2/3
+    assert abs(lam - 2.0 / 3.0) < 1e-12 and abs(tr.opt_G.lr - 2e-4 * lam) < 1e-12
+    path = str(tmp_path / "ckpt_e2.pt")
+    ck = tr.save_checkpoint(path, epoch=2)
+    # the reference's layout, key for key (train.py:127-137)
+    assert list(ck) == ["epoch", "G_A2B", "G_B2A", "D_A", "D_B", "optim_G", "optim_D_A", "optim_D_B"] and ck["epoch"] == 2
+    loaded = torch.load(path, map_location="cpu", weights_only=True)
+    G1, G2, D1, D2 = BG.build_models(cfg, "cpu")
+    for key, mod in (("G_A2B", G1), ("G_B2A", G2), ("D_A", D1), ("D_B", D2)):
+        assert list(loaded[key]) == list(mod.state_dict())
+        mod.load_state_dict(loaded[key])
+    # ... and torch.optim.Adam takes the optimiser states (what a user of the reference would do with the file)
+    ref_opt = torch.optim.Adam(list(G1.parameters()) + list(G2.parameters()), lr=2e-4, betas=(0.5, 0.999))
+    ref_opt.load_state_dict(loaded["optim_G"])
+    g0 = ref_opt.param_groups[0]
+    assert abs(g0["lr"] - 2e-4 * lam) < 1e-12 and g0["initial_lr"] == 2e-4 and len(ref_opt.state) == len(list(G1.parameters())) * 2
+    p0 = list(G1.parameters())[0]
+    assert float(ref_opt.state[p0]["step"]) == 2.0
+    np.testing.assert_array_equal(ref_opt.state[p0]["exp_avg"].numpy(), tr.opt_G.flat_m[:p0.numel()].cpu().view(p0.shape).numpy())
+    # continuation: original vs resumed
+    l_orig = tr.train_iteration(a, b)
+    tr2, _ = fresh()
+    assert tr2.load_checkpoint(path) == 2 and tr2.sched_epoch == 2 and abs(tr2.opt_G.lr - 2e-4 * lam) < 1e-12
+    l_res = tr2.train_iteration(a, b)
+    assert l_orig == l_res, (l_orig, l_res)
+    for o1, o2 in ((tr.opt_G, tr2.opt_G), (tr.opt_DA, tr2.opt_DA), (tr.opt_DB, tr2.opt_DB)):
+        assert torch.equal(o1.flat_p, o2.flat_p) and torch.equal(o1.flat_m, o2.flat_m) and torch.equal(o1.steps, o2.steps)
+    # the decayed rate really drives the update: Adam's third step moves a weight by ~lr * lam (sign-like early steps)
+    tr3, _ = fresh()
+    tr3.load_checkpoint(path)
+    tr3.opt_G.set_lr(2e-4)
+    before = tr3.opt_G.flat_p.clone()
+    tr3.train_iteration(a, b)
+    full = (tr3.opt_G.flat_p - before).abs().max()
+    dec = (tr2.opt_G.flat_p - before).abs().max()
+    assert abs(float(dec / full) - lam) < 0.02, float(dec / full)
+    return tr

@@ -679,9 +679,24 @@ class EmuOps:
     def patchnce_bwd(self, tgt, ids, P, Cc, temperature, weight, gtgt, ws):
         def op():
             src = self._nce_src[ws.data_ptr()]
-            with torch.enable_grad():   # the op may run inside an autograd.Function.forward, where grad mode is off
-                l, t, (ys, xs) = self._nce(src, tgt, ids, Cc, temperature)
-                (g,) = torch.autograd.grad(l * weight, t)
+            # closed form (no autograd here: the op may run below the dispatcher's autograd layer, where nothing records):
+            # dL/dlogits = (softmax - onehot) / (B P), zero where the clamp is active; through the division by T and the normalisation of t
+            W_ = tgt.W
+            ys, xs = ids.long() // W_, ids.long() % W_
+            t = tgt.nhwc().float()[:, ys, xs, :Cc]
+            sfeat = src.nhwc().float()[:, ys, xs, :Cc]
+            sn = torch.nn.functional.normalize(sfeat, dim=2, eps=1e-6)
+            nt = t.norm(dim=2, keepdim=True).clamp_min(1e-6)
+            tn = t / nt
+            raw = torch.bmm(tn, sn.transpose(1, 2)) / temperature
+            logits = raw.clamp(-50, 50)
+            B_, P_ = logits.shape[:2]
+            per = torch.nn.functional.cross_entropy(logits.reshape(B_ * P_, P_), torch.arange(P_).repeat(B_), reduction="none").reshape(B_, P_).mean(1)
+            dlog = (torch.softmax(logits, dim=2) - torch.eye(P_).unsqueeze(0)) / (B_ * P_)
+            dlog = dlog * ((raw > -50) & (raw < 50)) * torch.isfinite(per).view(B_, 1, 1)
+            dtn = torch.bmm(dlog, sn) / temperature
+            g = weight * (dtn - tn * (dtn * tn).sum(2, keepdim=True)) / nt
+            g = torch.where(t.norm(dim=2, keepdim=True) > 1e-6, g, weight * dtn / 1e-6)
             buf = gtgt.nhwc()
             acc = buf.float()
             for i in range(ids.numel()):
@@ -693,23 +708,40 @@ class EmuOps:
     def make_adam_table(self, entries):
         return entries  # the emulator keeps the python dicts
 
-    def adam_step(self, table, ntensors, chunk_tensor, chunk_off, nchunks, lr, b1, b2, eps, max_norm, grad_scale, ema_decay, norm_out, ws):
+    def adam_step(self, table, ntensors, chunk_tensor, chunk_off, nchunks, lr, b1, b2, eps, max_norm, grad_scale, ema_decay, norm_out, ws,
+                  lr_dev=None, inv_scale=None, skip_nonfinite=False):
         def op():
+            gs = grad_scale * (float(inv_scale) if inv_scale is not None else 1.0)
+            rate = float(lr_dev) if lr_dev is not None else lr
             live = [e for e in table if e.get("g") is not None]
-            tot = math.sqrt(sum(float(((e["g"] * grad_scale) ** 2).sum()) for e in live))
+            tot = math.sqrt(sum(float(((e["g"] * gs) ** 2).sum()) for e in live))
             coef = min(1.0, max_norm / (tot + 1e-6)) if max_norm > 0 else 1.0
-            norm_out[0], norm_out[1] = tot, coef
+            found = not math.isfinite(tot)
+            norm_out[0], norm_out[1], norm_out[2] = tot, coef, float(found)
+            if skip_nonfinite and found:
+                return
             for e in live:
-                g = e["g"] * (grad_scale * coef)
+                g = e["g"] * (gs * coef)
                 t = int(e["step"]) + 1
                 e["step"].fill_(t)
                 e["m"].lerp_(g, 1 - b1)
                 e["v"].mul_(b2).addcmul_(g, g, value=1 - b2)
                 bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
                 denom = (e["v"].sqrt() / math.sqrt(bc2)).add_(eps)
-                e["p"].addcdiv_(e["m"], denom, value=-(lr / bc1))
+                e["p"].addcdiv_(e["m"], denom, value=-(rate / bc1))
                 if e.get("ema") is not None:
                     e["ema"].copy_((1.0 - ema_decay) * e["p"] + ema_decay * e["ema"])
+        return op
+
+    def scaler_update(self, scale, inv_scale, tracker, found_inf, growth=2.0, backoff=0.5, interval=2000):
+        def op():
+            if float(found_inf) != 0.0:
+                scale.mul_(backoff); tracker.zero_()
+            elif int(tracker) + 1 >= interval:
+                scale.mul_(growth); tracker.zero_()
+            else:
+                tracker.add_(1)
+            inv_scale.copy_(1.0 / scale)
         return op
 
     def fill(self, t, value):

@@ -16,9 +16,9 @@ from tests.emulator import EmuOps
 S, BG = 32, 2
 
 
-def _inputs():
+def _inputs(bg=BG):
     g = torch.Generator().manual_seed(1234)
-    return torch.rand(BG, 3, S, S, generator=g) * 2 - 1, torch.rand(BG, 3, S, S, generator=g) * 2 - 1
+    return torch.rand(bg, 3, S, S, generator=g) * 2 - 1, torch.rand(bg, 3, S, S, generator=g) * 2 - 1
 
 
 def _global_randomness(tr_like):
@@ -47,11 +47,15 @@ def _bucket_op_index(tr):
     return idx[0]
 
 
-def _worker(rank, world, port, out, early=False):
+def _worker(rank, world, port, out, early=False, bg=BG):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
-    bl = BG // world
+    # the registered bucket op (torch.ops.mi355x_gan.allreduce_bucket_) on this group: SUM in place
+    from gan_variant_research_amd import ops_library  # noqa: F401
+    flat = torch.full((5,), float(rank + 1))
+    assert torch.ops.mi355x_gan.allreduce_bucket_(flat, "").tolist() == [world * (world + 1) / 2.0] * 5
+    bl = bg // world
     calls = []
     orig = C.CutTrainer._bucket_start
 
@@ -66,8 +70,8 @@ def _worker(rank, world, port, out, early=False):
     if early:      # the defect the test must catch: the tail bucket reduced before its weight gradients / bias sums are complete
         ops = tr.prog_g_compute.ops
         ops.insert(0, ops.pop(i[0]))
-    photos, monets = _inputs()
-    ref = _make(BG)                      # only used to draw the GLOBAL randomness with the same consumption order
+    photos, monets = _inputs(bg)
+    ref = _make(bg)                      # only used to draw the GLOBAL randomness with the same consumption order
     rnd = _shard(_global_randomness(ref), rank * bl, (rank + 1) * bl)
     losses = tr.train_step(0, photos[rank * bl:(rank + 1) * bl], monets[rank * bl:(rank + 1) * bl], rnd)
     assert calls == [tr._bucket_off], calls          # the two-bucket path ran (once), not the single all-reduce
@@ -79,30 +83,34 @@ def _worker(rank, world, port, out, early=False):
     dist.destroy_process_group()
 
 
-def _run_two_ranks(early=False):
+def _run_ranks(world=2, early=False, bg=BG):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, port, out, early), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, out, early, bg), nprocs=world, join=True)
     return out
+
+
+def _run_two_ranks(early=False):
+    return _run_ranks(2, early)
 
 
 _single = {}
 
 
-def _single_rank():
-    if not _single:
+def _single_rank(bg=BG):
+    if bg not in _single:
         torch.set_num_threads(4)
-        tr = _make(BG)
-        photos, monets = _inputs()
-        _single["tr"], _single["losses"] = tr, tr.train_step(0, photos, monets, _global_randomness(tr))
-    return _single["tr"], _single["losses"]
+        tr = _make(bg)
+        photos, monets = _inputs(bg)
+        _single[bg] = (tr, tr.train_step(0, photos, monets, _global_randomness(tr)))
+    return _single[bg]
 
 
-def _grad_err(two, one):
-    return float((two / 2 - one).abs().max() / one.abs().max())
+def _grad_err(summed, one, world=2):
+    return float((summed / world - one).abs().max() / one.abs().max())
 
 
 def test_two_ranks_equal_one_rank():
@@ -130,3 +138,16 @@ def test_tail_bucket_issued_too_early_is_caught():
     off = out["bucket_off"]
     assert _grad_err(out["flat_g"][:off], single.opt_G.flat_g[:off]) < 2e-4        # the head bucket is still right
     assert _grad_err(out["flat_g"][off:], single.opt_G.flat_g[off:]) > 1e-2        # the tail is not
+
+
+def test_four_ranks_equal_one_rank():
+    """Sharding and the 1/N scaling beyond N = 2 (BASELINE configs[3] runs N = 8): four ranks with one image each of a global batch of
+    four -- the summed gradient blocks (two-bucket generator path, asynchronous gloo collectives) against the one-rank gradient of the
+    whole batch, and the rank-mean of the batch-mean losses against the one-rank losses."""
+    out = _run_ranks(4, bg=4)
+    single, ref_losses = _single_rank(4)
+    assert _grad_err(out["flat_g"], single.opt_G.flat_g, 4) < 2e-4
+    assert _grad_err(out["flat_gd"], single.opt_D.flat_g, 4) < 2e-4
+    for k in ("d_loss", "g_adv", "nce", "identity", "r1"):
+        avg = sum(out[f"loss{r}"][k] for r in range(4)) / 4.0
+        np.testing.assert_allclose(avg, ref_losses[k], rtol=2e-4, atol=2e-5, err_msg=k)

@@ -184,3 +184,56 @@ def test_cut_step_bf16_backward_chain_on_emulator(monkeypatch):
     assert tr1.p2.bwd_chain and not tr2.p2.bwd_chain
     err = float((tr1.opt_G.flat_g - tr2.opt_G.flat_g).norm() / tr2.opt_G.flat_g.norm())
     assert err < 3e-2, err
+
+
+def test_lambda_rule_and_scheduler_match_the_reference(golden):
+    """Basic_GAN/src/train.py:27-31 and torch's LambdaLR on it (reference-generated basic_sched.npz): lambda_rule value for value, and the
+    learning-rate sequence CycleGANTrainer.scheduler_step() hands its three fused optimisers."""
+    from gan_variant_research_amd import basic as BG
+    g = golden("basic_sched.npz")
+    for key in [k for k in g if k.startswith("lambda.")]:
+        _, start, total = key.split(".")
+        want = g[key]
+        got = [BG.lambda_rule(e, int(start), int(total)) for e in range(len(want))]
+        assert got == [float(w) for w in want], key
+    cfg = cases.basic_config()
+    cfg["training"].update({"epochs": 6})
+    cfg["optim"]["lr_decay_after"] = 3
+    torch.manual_seed(0)
+    mods = BG.build_models(cfg, "cpu")
+    tr = BG.CycleGANTrainer(*mods, cfg, 1, 16, device="cpu", amp=False, ops=EmuOps())
+    seq = [tr.opt_G.lr]
+    for _ in range(7):
+        tr.scheduler_step()
+        seq.append(tr.opt_G.lr)
+        assert tr.opt_DA.lr == tr.opt_G.lr == tr.opt_DB.lr and float(tr.opt_G.lr_dev) == np.float32(tr.opt_G.lr)
+    np.testing.assert_allclose(seq, g["lr_seq.3.6"], rtol=1e-15, atol=0)
+    assert tr.opt_G.base_lr == float(g["initial_lr"])
+
+
+def test_basic_gan_checkpoint_round_trip(tmp_path):
+    cases.run_basic_checkpoint_case("cpu", EmuOps, tmp_path)
+
+
+def test_fused_adam_gradscaler_semantics():
+    """gan_adam_step's GradScaler knobs on the emulator (the HIP twin runs in test_gpu_parity): gradients are unscaled by the device-side
+    1/scale, an overflow skips the update and the step counters and raises found_inf, gan_scaler_update backs the scale off / grows it."""
+    ops = EmuOps()
+    p, g, m, v = torch.ones(8), torch.full((8,), 512.0), torch.zeros(8), torch.zeros(8)
+    step = torch.zeros(1, dtype=torch.int32)
+    table = ops.make_adam_table([{"p": p, "g": g, "m": m, "v": v, "ema": None, "step": step}])
+    norm, ws = torch.zeros(4), torch.zeros(32)
+    scale, inv, tracker = torch.tensor([1024.0]), torch.tensor([1.0 / 1024.0]), torch.zeros(1, dtype=torch.int32)
+    ct, co = torch.zeros(1, dtype=torch.int32), torch.zeros(1, dtype=torch.int64)
+    step_op = ops.adam_step(table, 1, ct, co, 1, 1e-3, 0.5, 0.999, 1e-8, 0.0, 1.0, 0.0, norm, ws, inv_scale=inv, skip_nonfinite=True)
+    upd = ops.scaler_update(scale, inv, tracker, norm[2:3], 2.0, 0.5, 2)
+    step_op(); upd()
+    assert abs(float(norm[0]) - 0.5 * 8 ** 0.5) < 1e-6 and float(norm[2]) == 0 and int(step) == 1 and float(scale) == 1024.0 and int(tracker) == 1
+    assert torch.allclose(p, torch.full((8,), 1.0 - 1e-3), atol=1e-6)
+    g[3] = float("inf")
+    before = p.clone()
+    step_op(); upd()
+    assert float(norm[2]) == 1 and int(step) == 1 and torch.equal(p, before) and float(scale) == 512.0 and int(tracker) == 0
+    g.fill_(256.0)
+    step_op(); upd(); step_op(); upd()
+    assert int(step) == 3 and float(scale) == 1024.0 and abs(float(inv) - 1.0 / 1024.0) < 1e-12

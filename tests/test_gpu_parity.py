@@ -568,11 +568,14 @@ def test_ops_library_hip(monkeypatch):
     """torch.ops.mi355x_gan.* on the kernels: the generator and discriminator assembled layer by layer from the op-level drop-in modules
     reproduce the reference's own outputs (golden) and the oracle's gradients; the fused clip+Adam+EMA op matches torch.optim.Adam."""
     from gan_variant_research_amd import ops_library as L, training as T
-    from tests.test_ops_library import fused_adam_case, layerwise_cases
+    from tests.test_ops_library import fused_adam_case, layerwise_cases, new_op_cases
+    from gan_variant_research_amd import losses as LS
     monkeypatch.setattr(L, "_PLANS", {})
+    monkeypatch.setattr(LS, "_PLANS", {})
     monkeypatch.setattr(T, "_FUSED_PLANS", {})
     layerwise_cases(torch.device(DEV), 1e-3)
     fused_adam_case(torch.device(DEV))
+    new_op_cases(torch.device(DEV), 1e-4)       # patchnce_fwd/_bwd, diffaugment_fwd/_bwd vs the reference's golden vectors, allreduce_bucket_
 
 
 def test_inference_chain_vs_oracle(tmp_path):
@@ -768,3 +771,87 @@ def test_conv_backward_chain_epilogue(bm, bn, H, monkeypatch):
     scale = sums[0].abs().max()
     np.testing.assert_allclose(sums[1].numpy(), sums[0].numpy(), rtol=2e-2, atol=float(scale) * 2e-3)
     np.testing.assert_allclose(d1g.t.float().cpu().numpy(), d2g.t.float().cpu().numpy(), rtol=2e-2, atol=2e-2)
+
+
+def test_basic_gan_checkpoint_continuation_hip(tmp_path):
+    """SURVEY §8f-1 for the CycleGAN trainer on the GPU (Basic_GAN/src/train.py:27-31,54-58,124-137): the reference's checkpoint dict, its
+    LambdaLR schedule as one device float per fused optimiser, and a bit-identical continuation after load_checkpoint."""
+    cases.run_basic_checkpoint_case(DEV, lambda: HipOps(torch.device(DEV)), tmp_path)
+
+
+def test_adam_gradscaler_knobs_twins():
+    """gan_adam_step's lr_dev / inv_scale_dev / skip_nonfinite and gan_scaler_update (torch.amp.GradScaler's unscale_, step, update:
+    amp_utils.py:29-41) on the GPU against the CPU statement: clean step, overflow step (update and step counters skipped, scale backed
+    off), growth after the interval, learning rate read from the device."""
+    res = []
+    for ops, dev in ((EmuOps(), "cpu"), (HipOps(torch.device(DEV)), DEV)):
+        gen = torch.Generator().manual_seed(3)
+        p = torch.randn(40000, generator=gen).to(dev)
+        g = (torch.randn(40000, generator=gen) * 300).to(dev)
+        m, v, ema = torch.zeros_like(p), torch.zeros_like(p), p.clone()
+        step = torch.zeros(1, dtype=torch.int32, device=dev)
+        table = ops.make_adam_table([{"p": p, "g": g, "m": m, "v": v, "ema": ema, "step": step}])
+        ct = torch.tensor([0, 0, 0], dtype=torch.int32, device=dev)
+        co = torch.tensor([0, 16384, 32768], dtype=torch.int64, device=dev)
+        norm, ws = torch.zeros(4, device=dev), torch.zeros(32, device=dev)
+        scale, inv = torch.tensor([256.0], device=dev), torch.tensor([1.0 / 256.0], device=dev)
+        tracker, lr_dev = torch.zeros(1, dtype=torch.int32, device=dev), torch.tensor([3e-3], device=dev)
+        step_op = ops.adam_step(table, 1, ct, co, 3, 1.0, 0.5, 0.999, 1e-8, 5.0, 1.0, 0.9, norm, ws, lr_dev=lr_dev, inv_scale=inv, skip_nonfinite=True)
+        upd = ops.scaler_update(scale, inv, tracker, norm[2:3], 2.0, 0.5, 2)
+        log = []
+        for it in range(4):
+            if it == 1:
+                g[123] = float("nan")
+            if it == 2:
+                g[123] = 1.0
+                lr_dev.fill_(1e-3)
+            step_op(); upd()
+            log.append(torch.cat([norm[:3].cpu(), scale.cpu(), step.float().cpu(), tracker.float().cpu()]))
+        res.append((p.cpu(), m.cpu(), v.cpu(), ema.cpu(), torch.stack(log)))
+    for a, b in zip(res[0][:4], res[1][:4]):
+        np.testing.assert_allclose(b.numpy(), a.numpy(), rtol=2e-5, atol=2e-6)
+    la, lb = res[0][4], res[1][4]
+    assert torch.isnan(lb[1, 0]) and lb[1, 2] == 1 and lb[1, 3] == 128.0 and lb[1, 4] == 1           # overflow: skipped, scale halved
+    np.testing.assert_allclose(np.nan_to_num(lb.numpy(), nan=-1.0), np.nan_to_num(la.numpy(), nan=-1.0), rtol=2e-5)
+    assert lb[3, 4] == 3 and lb[3, 3] == 256.0                                                       # two clean steps: grown back
+
+
+def test_caller_streams_are_ordered_with_the_bound_stream():
+    """A trainer launches on the stream it was bound to at construction; its inputs may be produced on ANOTHER stream (a prefetch stream,
+    `with torch.cuda.stream(s)`) and its results read there.  train_step must order the two (wait_stream both ways), and the op-level
+    library must build its plan for the stream that is current at the call: results equal those of the plain default-stream run."""
+    from gan_variant_research_amd import cut as C, ops_library as L  # noqa: F401
+    cfg = cases.small_config()
+    cfg["model"]["generator"]["ngf"], cfg["model"]["discriminator"]["ndf"] = 16, 16
+    B, S = 2, 64
+
+    def make():
+        C.set_seed(42)
+        gen, disc = C.build_models(cfg, "cpu")
+        return C.CutTrainer(gen, disc, cfg, B, S, device=DEV, amp=False)
+    g = torch.Generator().manual_seed(3)
+    ph, mo = (torch.rand(B, 3, S, S, generator=g) * 2 - 1), (torch.rand(B, 3, S, S, generator=g) * 2 - 1)
+    tr = make()
+    ref = tr.train_step(0, ph.to(DEV), mo.to(DEV), tr.sample_randomness(torch.Generator().manual_seed(9)))
+    tr2 = make()
+    side = torch.cuda.Stream()
+    big = torch.randn(4096, 4096, device=DEV)
+    with torch.cuda.stream(side):
+        for _ in range(20):                      # keeps `side` busy: the inputs below are ready long after the host reaches train_step
+            big = big @ big * 1e-4
+        p2 = ph.to(DEV, non_blocking=True) + 0 * big[0, 0]
+        m2 = mo.to(DEV, non_blocking=True) + 0 * big[0, 1]
+        got = tr2.train_step(0, p2, m2, tr2.sample_randomness(torch.Generator().manual_seed(9)))
+        fake_side = tr2.generated().clone()      # read on the caller's stream right after the step
+    torch.cuda.synchronize()
+    assert got == ref and torch.equal(fake_side, tr.generated())
+    # op-level library: the same op from two streams (two plans), both equal to F.conv2d
+    x, w = torch.randn(2, 16, 12, 12, device=DEV), torch.randn(8, 16, 3, 3, device=DEV) * 0.1
+    want = torch.nn.functional.conv2d(x.cpu(), w.cpu(), padding=1)
+    y0 = torch.ops.mi355x_gan.conv2d_fwd(x, w, None, 1, 1, L.PAD_ZERO, 0)
+    with torch.cuda.stream(side):
+        xs = x + 0 * (big @ big)[0, 0]
+        y1 = torch.ops.mi355x_gan.conv2d_fwd(xs, w, None, 1, 1, L.PAD_ZERO, 0)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y0.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
+    assert torch.equal(y0, y1)

@@ -54,7 +54,7 @@ def test_argument_validation_messages():
     assert lib.gan_in_stats(C.byref(v), C.c_float(1e-5), None, None, None) < 0 and lib.gan_last_error()
     assert lib.gan_patchnce_ws_floats(2, 16, 64) == 3 * 2 * 16 * 64 + 3 * 2 * 16 + 4 + 64
     assert lib.gan_adam_step(None, 0, None, None, 0, C.c_float(1e-3), C.c_float(0.5), C.c_float(0.999), C.c_float(1e-8), C.c_float(0), C.c_float(1),
-                             C.c_float(0), None, None, None) < 0
+                             C.c_float(0), None, None, 0, None, None, None) < 0
     assert lib.gan_pack_weight_batch(None, 0, 0, None) < 0 and b"pack_weight_batch" in lib.gan_last_error()
 
 

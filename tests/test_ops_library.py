@@ -121,12 +121,64 @@ def fused_adam_case(device):
             e.mul_(0.999).add_(r.detach(), alpha=0.001)
         for dst, gr in zip(gs, grads):
             dst.copy_(gr)
-        norm = torch.ops.mi355x_gan.fused_clip_adam_ema_(ps, gs, m, v, ema, steps, 2e-4, 0.5, 0.999, 1e-8, 10.0, 1.0, 0.999)
+        fresh = [gr.clone().to(device) for gr in grads]       # new gradient tensors every step, as zero_grad(set_to_none=True) leaves them
+        norm, found_inf = torch.ops.mi355x_gan.fused_clip_adam_ema_(ps, fresh, m, v, ema, steps, 2e-4, 0.5, 0.999, 1e-8, 10.0, 1.0, 0.999)
         np.testing.assert_allclose(float(norm), float(want_norm), rtol=1e-5)
+        assert float(found_inf) == 0.0
         for p, r, e, er in zip(ps, ref, ema, ema_ref):
             np.testing.assert_allclose(p.cpu().numpy(), r.detach().numpy(), rtol=1e-5, atol=1e-7)
             np.testing.assert_allclose(e.cpu().numpy(), er.numpy(), rtol=1e-5, atol=1e-7)
     assert steps.tolist() == [3, 3, 3]
+    from gan_variant_research_amd import training as T
+    assert len(T._FUSED_PLANS) == 1, "one prebuilt launch per optimiser state, whatever the gradients' addresses"
+    # GradScaler semantics through the op: an overflow skips the step and reports found_inf
+    bad = [g.clone() for g in fresh]
+    bad[0].view(-1)[0] = float("inf")
+    before = [p.clone() for p in ps]
+    inv = torch.full((1,), 0.5, device=device)
+    norm, found_inf = torch.ops.mi355x_gan.fused_clip_adam_ema_(ps, bad, m, v, ema, steps, 2e-4, 0.5, 0.999, 1e-8, 10.0, 1.0, 0.999, inv, True)
+    assert float(found_inf) == 1.0 and steps.tolist() == [3, 3, 3] and all(torch.equal(a, b) for a, b in zip(ps, before))
+
+
+def new_op_cases(device, tol):
+    """torch.ops.mi355x_gan.patchnce_fwd / _bwd and diffaugment_fwd / _bwd, called DIRECTLY, against the reference's own values
+    (tests/golden/cut_losses.npz: PatchNCELoss._compute_nce_loss and DiffAugment of the imported reference, values and gradients), and
+    allreduce_bucket_ in a single process (no group: the bucket is returned untouched)."""
+    import os
+    from gan_variant_research_amd import cut as C
+    from gan_variant_research_amd import ops_library as L  # noqa: F401
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cut_losses.npz"))
+    for tag in ("a", "b", "c"):
+        src = torch.tensor(g[f"nce.{tag}.src"]).to(device)
+        tgt = torch.tensor(g[f"nce.{tag}.tgt"]).to(device).requires_grad_(True)
+        ids = torch.tensor(g[f"nce.{tag}.ids"]).to(device)
+        loss, saved = torch.ops.mi355x_gan.patchnce_fwd(src, tgt, ids, 0.07)
+        np.testing.assert_allclose(float(loss.detach()), float(g[f"nce.{tag}.loss"]), rtol=tol)
+        (gt,) = torch.autograd.grad(loss * 1.0, tgt)
+        want = g[f"nce.{tag}.gtgt"]
+        np.testing.assert_allclose(gt.cpu().numpy(), want, rtol=1e-3, atol=1e-3 * float(np.abs(want).max()))     # fp32 softmax of 256 logits, summation order
+        np.testing.assert_allclose(torch.ops.mi355x_gan.patchnce_bwd(saved.detach(), torch.tensor(2.0, device=device)).cpu().numpy(), 2.0 * gt.cpu().numpy(), rtol=1e-6, atol=1e-9)
+    # DiffAugment: the draws of the reference's run (global generator seeded with aug.seed), then the op on the parameter table
+    x = torch.tensor(g["aug.x"]).to(device).requires_grad_(True)
+    aug = C.DiffAugment(["color", "translation", "cutout"])
+    torch.manual_seed(int(g["aug.seed"]))
+    draws = aug.sample(3, 32, 32, None)
+    prm = aug.to_params(draws, 3, 32, 32).to(device)
+    y = torch.ops.mi355x_gan.diffaugment_fwd(x, prm)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["aug.y"], rtol=0, atol=max(tol, 2e-6))
+    (gx,) = torch.autograd.grad((y * torch.tensor(g["aug.w"]).to(device)).sum(), x)
+    np.testing.assert_allclose(gx.cpu().numpy(), g["aug.gx"], rtol=0, atol=max(tol, 2e-6) * 10)
+    np.testing.assert_allclose(torch.ops.mi355x_gan.diffaugment_bwd(torch.tensor(g["aug.w"]).to(device), prm).cpu().numpy(), g["aug.gx"], rtol=0, atol=max(tol, 2e-6) * 10)
+    flat = torch.arange(8, dtype=torch.float32, device=device)
+    out = torch.ops.mi355x_gan.allreduce_bucket_(flat, "")
+    assert out.data_ptr() == flat.data_ptr() and flat.tolist() == list(range(8))
+
+
+def test_new_ops_on_emulator(monkeypatch):
+    from gan_variant_research_amd import losses as LS
+    monkeypatch.setattr(AG, "_OPS_FACTORY", lambda device: EmuOps())
+    monkeypatch.setattr(LS, "_PLANS", {})
+    new_op_cases(torch.device("cpu"), 2e-5)
 
 
 def pad_op_cases(device):
@@ -157,7 +209,7 @@ def test_ops_are_registered_with_schemas():
     from gan_variant_research_amd import ops_library as L  # noqa: F401
     for name in ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad", "conv_transpose2d_fwd", "conv_transpose2d_dgrad", "conv_transpose2d_wgrad",
                  "instance_norm_fwd", "instance_norm_bwd", "reflection_pad2d", "reflection_pad2d_bwd", "replication_pad2d", "replication_pad2d_bwd",
-                 "fused_clip_adam_ema_"):
+                 "fused_clip_adam_ema_", "patchnce_fwd", "patchnce_bwd", "diffaugment_fwd", "diffaugment_bwd", "allreduce_bucket_"):
         op = getattr(torch.ops.mi355x_gan, name)
         assert "Tensor" in str(op.default._schema), name
 

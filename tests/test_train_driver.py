@@ -73,10 +73,13 @@ def test_driver_runs_checkpoints_and_resumes(tmp_path, source):
     ckpt = torch.load(os.path.join(ck, "ckpt_final.pt"), weights_only=True)
     assert ckpt["step"] == 2 and {"generator", "discriminator", "opt_G", "opt_D", "ema_G", "config", "metrics", "scaler"} <= set(ckpt)
     assert "initial.1.weight" in ckpt["generator"] and "shadow" in ckpt["ema_G"]
-    rows = open(os.path.join(lg, "training_losses.csv")).read().strip().splitlines()
+    rows = open(os.path.join(lg, "losses_history.csv")).read().strip().splitlines()
     assert rows[0] == "step,d_loss,g_loss" and [ln.split(",")[0] for ln in rows[1:]] == ["0", "1"]
     assert open(os.path.join(lg, "train_log.txt")).read().startswith("Step 1: {")
     # --resume continues at the stored step with the stored optimiser state
     r2 = T.main(["--config", cfg_path, "--synthetic", "--resume", os.path.join(ck, "ckpt_final.pt"), "--set"] + sets + ["max_steps=3"], ops=EmuOps(), device="cpu")
     assert r2["step"] == 3
     assert yaml.safe_load(open(cfg_path))["batch_size"] == 12       # the file itself is never rewritten
+    # a wrong data path is an error (as in the reference), not a silent run on noise: the synthetic batches need the explicit flag
+    with pytest.raises(FileNotFoundError, match="photos_dir"):
+        T.main(["--config", cfg_path, "--set"] + sets + ["data.photos_dir=/nonexistent/photos"], ops=EmuOps(), device="cpu")
