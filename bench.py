@@ -95,6 +95,11 @@ def dominant_kernel_roofline(trainer, iters=10):
     res_flops = 2.0 * x.B * y.H * y.W * conv.cout * conv.cin * 9   # x.B = 2 x batch while the identity pass rides in the generator pass
     peak = PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
     ach = flops / (ms * 1e-3) / 1e12
+    # algorithmic HBM bytes of the same launches (every operand tensor once): input incl. its halo, output, weight copy
+    esz = {0: 4, 1: 2, 2: 1}
+    alg_bytes = sum(o.conv.B * o.conv.x.Hp * o.conv.x.Wp * o.conv.x.C * esz[o.conv.x.dtype] + o.conv.B * o.conv.Ho * o.conv.Wo * o.conv.Nst * esz[o.conv.out.dtype]
+                    + o.conv.Nw * o.conv.ntaps * o.conv.Cin * esz[o.conv.x.dtype] for o in calls)
+    step_flop = GFLOP_PER_IMAGE * 1e9 * trainer.B * (trainer.S / 256.0) ** 2      # the FLOP count scales with the pixel count
     # the HBM-bound side of the path: every InstanceNorm forward / backward launch of the step, replayed the same way;
     # achieved = algorithmic bytes (each operand tensor once) / elapsed
     norm = [o for p in progs if p is not None for o in p.ops if getattr(o, "hbm_bytes", None)]
@@ -104,10 +109,13 @@ def dominant_kernel_roofline(trainer, iters=10):
                         "frac": round(norm_bytes / (norm_ms * 1e-3) / 8e12, 4), "kernel": "in_apply / in_bwd_* (InstanceNorm forward and backward)",
                         "launches_per_step": len(norm), "bytes_per_step": norm_bytes, "ms_per_step": round(norm_ms, 4)}
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "traffic": pmc_traffic("conv_patch_kernel") if bf16 else None,
-            "kernel": ("conv_patch_kernel<..., FP8> (e4m3 launches)" if fp8 else "conv_patch_kernel") if bf16 else "conv_igemm_kernel<float,...>",
+            # PMC bytes exist for the configuration the committed passes ran (bf16, 256x256, batch 16): anything else reports null
+            "traffic": pmc_traffic("conv_patch") if (bf16 and not fp8 and trainer.S == 256 and trainer.B == 16) else None,
+            "traffic_algorithmic": round(alg_bytes / max(len(calls), 1)),
+            "kernel": ("conv_patch_kernel<..., FP8> (e4m3 launches)" if fp8 else "conv_patch_kernel (+ conv_patch_bwdchain_kernel: the same body with the "
+                       "backward-chain epilogue)") if bf16 else "conv_igemm_kernel<float,...>",
             "launches_per_step": len(calls), "flop_per_step": flops, "ms_per_launch": round(ms / max(len(calls), 1), 5),
-            "share_of_step_conv_flop": round(flops / (GFLOP_PER_IMAGE * 1e9 * trainer.B), 3),
+            "share_of_step_conv_flop": round(flops / step_flop, 3),
             "res_fwd_tflops": round(res_flops / (res_ms * 1e-3) / 1e12, 2), "res_fwd_ms": round(res_ms, 4)}
 
 
@@ -311,10 +319,14 @@ def main():
             "config": {"workload": f"CUT ResNet-9 G + PatchGAN D + PatchNCE + identity + lazy R1 + DiffAugment, {args.size}x{args.size}, "
                                    f"batch {args.batch} per GPU (BASELINE.json configs[{4 if args.fp8 else 2}])", "global_batch": args.batch * world,
                        "parallelism": f"dp{world}"},
-            "step_mfma_frac": round(ips / world * GFLOP_PER_IMAGE * (args.size / 256.0) ** 2 / 1e3 / peak, 4),
             "last_losses": last,
         }
         out["roofline"] = dominant_kernel_roofline(tr)
+        # the step's algorithmic FLOPs against the peak(s) they ran on: with --fp8 the e4m3 launches' share is priced at the fp8 peak
+        share8 = out["roofline"]["share_of_step_conv_flop"] if args.fp8 else 0.0
+        peak_mix = 1.0 / (share8 / PEAK_FP8_TFLOPS + (1.0 - share8) / peak)
+        out["step_mfma_frac"] = round(ips / world * GFLOP_PER_IMAGE * (args.size / 256.0) ** 2 / 1e3 / peak_mix, 4)
+        out["step_mfma_peak"] = round(peak_mix, 1)
         out["norm_hbm"] = getattr(tr, "norm_hbm", None)      # the HBM-bound kernels of the path, measured the same way
         print(f"[bench] gpu: {ips:.1f} images/s, {dt / args.steps * 1e3:.2f} ms/step; roofline {out['roofline']['achieved']} TFLOP/s", file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:     # the CPU baseline is reported at N=1 only
