@@ -855,3 +855,31 @@ def test_caller_streams_are_ordered_with_the_bound_stream():
     torch.cuda.synchronize()
     np.testing.assert_allclose(y0.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
     assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_in_bwd_parts_raw_sums_twins(dtype):
+    """gan_in_bwd_parts with parts_mode 2 (sum g, sum g x against the RAW norm input, in any number of partials): equal to the two-pass
+    gan_in_bwd on the same gradient, on the GPU and in the CPU statement."""
+    from gan_variant_research_amd._lib import ACT_NONE
+    B, H, W, Cc, NP = 3, 12, 20, 256, 4
+    tw = Twin(dtype, seed=13)
+    xc, xg = tw.view(B, H, W, Cc, 0)
+    gc, gg = tw.view(B, H, W, Cc, 1)
+    d1c, d1g = tw.view(B, H, W, Cc, 2, rand=False)
+    d2c, d2g = tw.view(B, H, W, Cc, 2, rand=False)
+    xf = xc.nhwc().float()
+    stc, stg = tw.f32(torch.stack([xf.mean((1, 2)), 1.0 / torch.sqrt(xf.var((1, 2), unbiased=False) + 1e-5)], -1).reshape(-1))
+    from tests.emulator import _fold
+    gf = _fold(gc, True)                                            # what the kernel folds from the padded gradient
+    rows = torch.chunk(torch.arange(H), NP)                         # NP partials per image: row bands
+    assert len(rows) == NP
+    parts = torch.stack([torch.stack([gf[:, r].sum((1, 2)), (gf[:, r] * xf[:, r]).sum((1, 2))], -1) for r in rows], 1).reshape(-1)   # [B][NP][C][2]
+    pc, pg = tw.f32(parts)
+    for ctx, x, g, d1, d2, st, p in ((tw.c, xc, gc, d1c, d2c, stc, pc), (tw.g, xg, gg, d1g, d2g, stg, pg)):
+        ctx.ops.in_bwd_parts(x, st, ACT_NONE, g, True, d1, p, NP, 2)()
+        ctx.ops.in_bwd(x, st, ACT_NONE, g, True, None, d2, ctx.f32(B * 96 * Cc * 2 + B * Cc * 2 + (B * 1024 + 32) * Cc))()
+    torch.cuda.synchronize()
+    rtol, atol = TOL[dtype]
+    tw.check(rtol, atol)
+    np.testing.assert_allclose(d1g.t.float().cpu().numpy(), d2g.t.float().cpu().numpy(), rtol=rtol, atol=atol)
