@@ -8,14 +8,18 @@ G forward, D step (+ lazy R1 every 16th step), G step with PatchNCE and identity
 on synthetic inputs already resident in HBM.  Rank 0 prints ONE JSON line.  Extra objects:
   roofline     -- the dominant kernel (conv_patch_kernel: all of its launches of one step) timed live with HIP events on the
                   launch stream, against the dense bf16 MFMA peak;
-  cpu_baseline -- the PyTorch-CPU oracle's train step timed on this host's cores on a bounded sample (B=2).
+  cpu_baseline -- the PyTorch-CPU oracle's train step timed on this host's cores on a bounded sample (B=2);
+  power        -- board power and firmware shader clock of this GPU during the timed steps (hwmon), beside the board's power cap:
+                  the step's MFMA kernels run power-limited, which bounds `roofline.frac` well below 1.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
+import threading
 import time
 
 import torch
@@ -26,6 +30,7 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
+PEAK_BF16_AT_CAP_TFLOPS = 1988.0   # bare MFMA loop on random bf16 at the 1400 W board limit (profiles/r03_mfma_power.txt, the faster of two boxes)
 PEAK_FP8_TFLOPS = 5000.0    # dense fp8 MFMA peak (v_mfma_scale_f32_16x16x128_f8f6f4), same guide
 # canonical algorithmic conv FLOPs of one step per image at 256^2 (identity on) = 935.9 GFLOP, MINUS what this build does not
 # execute: the reference's get_feature_layers also runs the second up-sampling layer, whose output no PatchNCE layer id reaches (ids stop
@@ -116,7 +121,11 @@ def dominant_kernel_roofline(trainer, iters=10):
                        "backward-chain epilogue)") if bf16 else "conv_igemm_kernel<float,...>",
             "launches_per_step": len(calls), "flop_per_step": flops, "ms_per_launch": round(ms / max(len(calls), 1), 5),
             "share_of_step_conv_flop": round(flops / step_flop, 3),
-            "res_fwd_tflops": round(res_flops / (res_ms * 1e-3) / 1e12, 2), "res_fwd_ms": round(res_ms, 4)}
+            "res_fwd_tflops": round(res_flops / (res_ms * 1e-3) / 1e12, 2), "res_fwd_ms": round(res_ms, 4),
+            # what the 1400 W board limit leaves of `peak` for bf16 MFMAs on non-zero data: a bare loop of v_mfma_f32_16x16x32_bf16 on random
+            # register operands, no memory traffic at all, measured on this pool (tools/probe/mfma_power.hip, profiles/r03_mfma_power.txt;
+            # two boxes: 1842 and 1988 TFLOP/s at 1.91 / 2.04 GHz) -- a reference measurement, not part of this run
+            "peak_at_power_cap": PEAK_BF16_AT_CAP_TFLOPS if (bf16 and not fp8) else None}
 
 
 def pmc_traffic(kernel_prefix):
@@ -198,6 +207,49 @@ def launch_ranks(n: int) -> None:
     sys.stdout.flush()
     if failed is not None:
         raise SystemExit(f"[bench] rank {procs.index(failed)} exited with code {failed.returncode}")
+
+
+class BoardPower(threading.Thread):
+    """Board power and firmware-reported shader clock of THIS GPU while the timed steps run: hwmon `power1_input` / `freq1_input` read
+    from sysfs every 20 ms by a host thread (no GPU call).  The MFMA kernels of the step run at the board's power limit (DESIGN 3.7:
+    the convolution alone draws the 1400 W cap and holds ~2.0-2.1 of its 2.4 GHz), so the bench line carries the evidence."""
+
+    def __init__(self, dev):
+        super().__init__(daemon=True)
+        self.node, self.halt, self.w, self.mhz = None, False, [], []
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+            for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+                if os.path.basename(os.path.realpath(os.path.join(h, "..", ".."))).startswith(want) and os.path.exists(h + "/power1_input"):
+                    self.node = h
+        except Exception:
+            self.node = None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except Exception:
+            return None
+
+    def run(self):
+        while not self.halt and self.node:
+            w, f = self._read(self.node + "/power1_input"), self._read(self.node + "/freq1_input")
+            if w is not None:
+                self.w.append(w * 1e-6)
+            if f is not None:
+                self.mhz.append(f * 1e-6)
+            time.sleep(0.02)
+
+    def report(self):
+        if not self.node or not self.w:
+            return None
+        cap = self._read(self.node + "/power1_cap")
+        return {"board_w": round(sum(self.w) / len(self.w), 1), "board_w_max": round(max(self.w), 1), "cap_w": round(cap * 1e-6, 1) if cap else None,
+                "sclk_mhz": round(sum(self.mhz) / len(self.mhz), 0) if self.mhz else None, "samples": len(self.w),
+                "source": "hwmon power1_input / freq1_input of this GPU, sampled every 20 ms during the timed steps"}
 
 
 def main():
@@ -292,6 +344,9 @@ def main():
         last = tr.train_step(step, photos, monets, tr.sample_randomness(aug_gen, nce_gen))
         step += 1
     barrier()
+    meter = BoardPower(dev) if rank == 0 else None
+    if meter is not None:
+        meter.start()
     t0 = time.perf_counter()
     # sync="lag": each step's loss dict (and NaN check) is delivered one call later, so the read-back of step k overlaps the
     # queueing of step k+1; flush_losses() inside the timed region collects the last one -- all K dicts are produced in the window
@@ -302,6 +357,9 @@ def main():
     last = tr.flush_losses() or last
     barrier()
     dt = time.perf_counter() - t0
+    if meter is not None:
+        meter.halt = True
+        meter.join()
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev)
@@ -321,6 +379,7 @@ def main():
                        "parallelism": f"dp{world}"},
             "last_losses": last,
         }
+        out["power"] = meter.report() if meter is not None else None
         out["roofline"] = dominant_kernel_roofline(tr)
         # the step's algorithmic FLOPs against the peak(s) they ran on: with --fp8 the e4m3 launches' share is priced at the fp8 peak
         share8 = out["roofline"]["share_of_step_conv_flop"] if args.fp8 else 0.0

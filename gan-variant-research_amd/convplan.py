@@ -209,6 +209,11 @@ class ConvLayer:
     # ------------------------------------------------------------------ weights
     def repack_ops(self):
         out = [op for pk in self.packs for op in pk.pack_ops(self.weight)]
+        if not out:
+            # the operand copies are allocated when a call is planned: a repack program built before any fwd / dgrad plan would pack
+            # nothing and the launches planned afterwards would multiply by zeros (measured that way, they also run ~20 % too fast:
+            # zero operands draw less power and the chip holds a higher clock)
+            raise GanError("ConvLayer.repack_ops: no operand copy is planned yet -- plan the forward / input-gradient calls first, then build the repack program")
         if self.bias_k is not self.bias:
             out.append(self.ctx.ops.pack_weight(self.bias, self.bias_k, F32, self.bias_k.numel(), 1, 1, self.cout, 1, False, 1, 1, self._one))
         if self.bias_pair is not None:

@@ -24,6 +24,7 @@
 //    emits the InstanceNorm statistics of its tile (gan_conv_desc.stats) with DPP row reductions.
 #include <stdlib.h>
 #include <type_traits>
+#include <array>
 #include <atomic>
 #include "common.h"
 
@@ -165,10 +166,17 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
 
   int nstamp = 0;
   auto stamp = [&]() {
-    if (a.stamps && wave == 0 && nstamp < 32) {
+    if (a.stamps && wave == 0 && nstamp < 30) {
       unsigned long long t;
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-      if (lane == 0) ((unsigned long long*)((uintptr_t)a.stamps & ~(uintptr_t)7))[blockIdx.x * 32 + nstamp] = t;
+      if (lane == 0) {
+        unsigned long long* sb = (unsigned long long*)((uintptr_t)a.stamps & ~(uintptr_t)7) + blockIdx.x * 32;
+        sb[nstamp] = t;
+        // slots 30 / 31: the 100 MHz wall counter at the first / latest stamp (in-kernel clock = d(s_memtime) / d(s_memrealtime) * 100 MHz)
+        const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+        if (nstamp == 0) sb[30] = rt;
+        sb[31] = rt;
+      }
       ++nstamp;
     }
   };
@@ -950,7 +958,14 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   a.mask_Hp = d->mask_Hp; a.mask_Wp = d->mask_Wp; a.mask_y0 = d->mask_y0; a.mask_x0 = d->mask_x0;
   // diagnostic environment (stamp buffer, static-schedule switch): read once per process, not per launch
   static unsigned long long* const stamps_env = [] { const char* e = getenv("GAN_PATCH_STAMPS"); return e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }();
-  a.stamps = stamps_env;
+  // GAN_PATCH_STAMPS_SEL="rows,cols,batch,chain,taps": only launches of that tile, batch and epilogue stamp (tools/step_clock.py reads one kernel
+  // of the running step)
+  static const std::array<int, 5> stamps_sel = [] {
+    std::array<int, 5> v{0, 0, 0, 0, 0};
+    if (const char* e = getenv("GAN_PATCH_STAMPS_SEL")) sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]);
+    return v;
+  }();
+  a.stamps = (stamps_sel[0] == 0 || (stamps_sel[0] == BM && stamps_sel[1] == BN && stamps_sel[2] == d->B && stamps_sel[3] == (a.smode != 0) && stamps_sel[4] == d->ntaps)) ? stamps_env : nullptr;
   const int grid = a.tiles < ncu ? a.tiles : ncu;
   // the dynamic-LDS limit is a per-device function attribute: one bit per device, set on that device's first launch
   static std::atomic<uint64_t> attr_devs{0};

@@ -1,5 +1,6 @@
 """Per-layer microbenchmark of the MFMA kernels at the bench shapes (B=16, 256x256 CUT): forward, dgrad, wgrad TFLOP/s."""
 import sys
+import time
 import torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gan_variant_research_amd import BF16, F32
@@ -12,9 +13,13 @@ dtype = BF16
 ctx = Ctx(HipOps(dev), dev, dtype)
 
 
-def timeit(ops, iters=10):
-    for _ in range(2):
-        for o in ops: o()
+def timeit(ops, iters=20, warm_s=0.5):
+    # MFMA kernels on real operands run at the board power limit: time them at the clock the chip settles at under their own load
+    t0 = time.time()
+    while time.time() - t0 < warm_s:
+        for _ in range(20):
+            for o in ops: o()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
@@ -38,7 +43,6 @@ for name, cin, cout, k, s, p, tr, H, reflect in LAYERS:
     w = torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k), device=dev) * 0.05
     b = torch.zeros(cout, device=dev)
     layer = ConvLayer(ctx, w, b, torch.zeros_like(w), torch.zeros_like(b), k, s, p, tr)
-    for o in layer.repack_ops(): o()
     Ho = 2 * H if tr else (H + 2 * p - k) // s + 1
     x = ctx.view(B, H, H, cpad(cin), max(p, 1)); x.t.normal_()
     y = ctx.view(B, Ho, Ho, cpad(cout), 0)
@@ -51,8 +55,10 @@ for name, cin, cout, k, s, p, tr, H, reflect in LAYERS:
     else:
         dy = ctx.view(B, Ho, Ho, cpad(cout), k - 1 - p); dx = ctx.view(B, H, H, cpad(cin), 0); dg = layer.dgrad(dy, dx)
     dy.t.normal_()
+    fw = layer.fwd(x, y)
+    for o in layer.repack_ops(): o()      # after planning: the operand copies exist only then (packed earlier, the launches would multiply by zeros)
     flop = 2.0 * B * (H * H if tr else Ho * Ho) * cin * cout * k * k / (4 if tr else 1) * (1 if not tr else 1)
     if tr:
         flop = 2.0 * B * H * H * cin * cout * 9
-    tf = timeit(layer.fwd(x, y)); td = timeit(dg); tw = timeit(layer.wgrad(x, dy, False, bias_too=False))
+    tf = timeit(fw); td = timeit(dg); tw = timeit(layer.wgrad(x, dy, False, bias_too=False))
     print(f"{name:28s} {flop/1e9:8.2f} {tf*1e3:8.1f} {flop/tf/1e9:7.1f} {td*1e3:9.1f} {flop/td/1e9:7.1f} {tw*1e3:9.1f} {flop/tw/1e9:7.1f}")
