@@ -344,7 +344,7 @@ def main():
         last = tr.train_step(step, photos, monets, tr.sample_randomness(aug_gen, nce_gen))
         step += 1
     barrier()
-    meter = BoardPower(dev) if rank == 0 else None
+    meter = BoardPower(dev) if (rank == 0 and not os.environ.get("GAN_NO_POWER_SAMPLER")) else None
     if meter is not None:
         meter.start()
     t0 = time.perf_counter()
