@@ -939,6 +939,12 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   a.nchunk = a.Cin / 64; a.ntaps = d->ntaps; a.KB = d->ntaps * a.Cin / 32;
   a.nslice = (patch_span(d, BM) + 63) / 64;
   a.w_bytes = d->Nw * d->ntaps * a.Cin * 2;
+  // 32-bit byte offsets everywhere (buffer descriptors; slab addresses): every operand tensor must stay below 4 GiB - 16 (a dropped store is
+  // sent to offset 2^32 - 16).  At 2 bytes x 256 channels that is ~490 images of a 130 x 130 padded map: far above any batch of this path.
+  const int64_t lim = (1ll << 32) - 16;
+  if ((int64_t)d->B * d->out_Hp * d->out_Wp * d->out_C * 2 > lim || (int64_t)d->B * d->in_Hp * d->in_Wp * (fp8 ? d->Cin : d->Cin * 2) > lim ||
+      (d->mask && (int64_t)d->B * d->mask_Hp * d->mask_Wp * d->out_C * 2 > lim))
+    return gan_set_error(-1, "conv_patch: an operand tensor exceeds the kernel's 32-bit byte offsets (4 GiB): split the batch");
   a.out_bytes = (uint32_t)((int64_t)d->B * d->out_Hp * d->out_Wp * d->out_C * 2);
   a.mask_bytes = d->mask ? (uint32_t)((int64_t)d->B * d->mask_Hp * d->mask_Wp * d->out_C * 2) : 0;
   a.in_Hp = d->in_Hp; a.in_Wp = d->in_Wp; a.in_y0 = d->in_y0; a.in_x0 = d->in_x0; a.in_sy = d->in_sy; a.in_sx = d->in_sx;

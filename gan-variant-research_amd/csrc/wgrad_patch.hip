@@ -272,6 +272,9 @@ int gan_wgrad_patch_launch(const gan_wgrad_desc* d, hipStream_t s) {
   GAN_CHECK(spi_want > 0 ? d->nsplit == d->B * spi_want : d->nsplit * -spi_want == d->B, "wgrad_patch: nsplit=%d is not what gan_wgrad_patch_splits implies (%d)",
             d->nsplit, spi_want);
   GAN_CHECK(!(ring && a.ipb > 1), "wgrad_patch: the row-ring variant (128-pixel-wide maps) takes one image per split");
+  // the staging addresses are 32-bit byte offsets from the tensor bases
+  GAN_CHECK((int64_t)d->B * d->x_Hp * d->x_Wp * d->Cx * 2 < (1ll << 32) && (int64_t)d->B * d->g_Hp * d->g_Wp * d->g_C * 2 < (1ll << 32),
+            "wgrad_patch: an operand tensor exceeds the kernel's 32-bit byte offsets (4 GiB): split the batch");
   static std::atomic<uint64_t> attr_devs{0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return gan_set_error(-2, "wgrad_patch: hipGetDevice failed");
