@@ -116,18 +116,32 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(int P, int C, float inv_t,
 
 // per image: mean of row losses; non-finite -> 0 with flag 0 (patchnce_cut.py:97-99); *loss += weight * mean_b
 __global__ __launch_bounds__(256) void nce_finalize_kernel(int B, int P, float weight, NceWs w, float* __restrict__ loss) {
-  __shared__ float sh[16];
+  // one wave per image (a wave reduction, no block-wide barrier per image: 16 images took 14 us of barriers); the images' means are
+  // then added in image order by one thread, as before
+  __shared__ float sb[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float tot = 0.f;
-  for (int b = 0; b < B; ++b) {
-    float s = 0.f;
-    for (int i = threadIdx.x; i < P; i += 256) s += w.rowloss[(int64_t)b * P + i];
-    s = block_sum(s, sh) / (float)P;
-    const bool ok = isfinite(s);
-    if (threadIdx.x == 0) w.flag[b] = ok ? 1.f : 0.f;
-    tot += ok ? s : 0.f;
+  for (int b0 = 0; b0 < B; b0 += 256) {
+    const int nb = min(256, B - b0);
+    for (int k = wave; k < nb; k += 4) {
+      float s = 0.f;
+      for (int i = lane; i < P; i += 64) s += w.rowloss[(int64_t)(b0 + k) * P + i];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+      if (lane == 0) sb[k] = s / (float)P;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int k = 0; k < nb; ++k) {
+        const bool ok = isfinite(sb[k]);
+        w.flag[b0 + k] = ok ? 1.f : 0.f;
+        tot += ok ? sb[k] : 0.f;
+      }
+    }
+    __syncthreads();
   }
-  tot /= (float)B;
   if (threadIdx.x == 0) {
+    tot /= (float)B;
     if (!isfinite(tot)) tot = 0.f;  // :106-108
     *loss += weight * tot;
   }
@@ -200,15 +214,22 @@ __device__ __forceinline__ void nce_logits_mfma(const float* __restrict__ Sn_b, 
     pb[t] = Sn_b + (int64_t)min(64 * wave + 16 * t + fr, P - 1) * C + 4 * fg;
     acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
-  for (int q = 0; q < C; q += 16) {
-    const f32x4_t a4 = *reinterpret_cast<const f32x4_t*>(pa + q);
-    f32x4_t b4[4];
+  // C % 64 == 0 (nce_mfma_ok): four k-steps per trip, all their loads issued before the first MFMA (a rolled loop waits for every step's
+  // loads: a chain of C / 16 dependent L2 round trips)
+  for (int q = 0; q < C; q += 64) {
+    f32x4_t a4[4], b4[4][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) b4[t] = *reinterpret_cast<const f32x4_t*>(pb[t] + q);
+    for (int u = 0; u < 4; ++u) {
+      a4[u] = *reinterpret_cast<const f32x4_t*>(pa + q + 16 * u);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+      for (int t = 0; t < 4; ++t) b4[u][t] = *reinterpret_cast<const f32x4_t*>(pb[t] + q + 16 * u);
+    }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], b4[t][e], acc[t], 0, 0, 0);
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][e], b4[u][t][e], acc[t], 0, 0, 0);
   }
 }
 
@@ -278,7 +299,6 @@ __global__ __launch_bounds__(256) void nce_bwd_mfma_kernel(int B, int P, int C, 
   float* dsh = dyn;              // [TI][DP]  dLogits
   float* tsh = dsh + TI * DP;    // [TI][C]   normalised target rows
   float* gsh = tsh + TI * C;     // [TI][C]   dTn
-  __shared__ float red[16];
   const int b = blockIdx.y, i0 = blockIdx.x * TI;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
   const float* Sn_b = w.Sn + (int64_t)b * P * C;
@@ -308,31 +328,59 @@ __global__ __launch_bounds__(256) void nce_bwd_mfma_kernel(int B, int P, int C, 
   }
   __syncthreads();
   // dTn[i][c] = sum_j dLogits[i][j] * Sn[j][c]: wave owns channels wave*C/4 ..., 16 at a time; k = j, same permutation
-  const int cw = C >> 2;
-  for (int ct = 0; ct < cw; ct += 16) {
-    const int c0 = wave * cw + ct;
-    f32x4_t g = {0.f, 0.f, 0.f, 0.f};
-    const float* pb = Sn_b + (int64_t)(4 * fg) * C + c0 + fr;
-    for (int q = 0; q < P; q += 16) {
-      const f32x4_t a4 = *reinterpret_cast<const f32x4_t*>(dsh + fr * DP + q + 4 * fg);
-      float bv[4];
+  const int cw = C >> 2, nct = cw >> 4;          // C % 64 == 0, C <= 256: one to four 16-channel blocks per wave
+  {
+    f32x4_t g[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bv[e] = pb[(int64_t)(q + e) * C];
+    for (int k = 0; k < 4; ++k) g[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const float* pb = Sn_b + (int64_t)(4 * fg) * C + wave * cw + fr;
+    // four k-steps of all the wave's channel blocks per trip, their strided loads (up to 64) issued before the first MFMA: the rolled
+    // loops were a chain of (C / 64) x (P / 16) dependent L2 round trips (59 us per launch for 0.27 GFLOP; now 4 trips)
+    for (int q = 0; q < P; q += 64) {
+      float bv[4][4][4];
+      f32x4_t a4[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], bv[e], g, 0, 0, 0);
+      for (int u = 0; u < 4; ++u) {
+        const int qq = min(q + 16 * u, P - 16);       // P % 16 == 0; a step past the end re-reads the last one and is not multiplied
+        a4[u] = *reinterpret_cast<const f32x4_t*>(dsh + fr * DP + qq + 4 * fg);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < nct) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[k][u][e] = pb[(int64_t)(qq + e) * C + 16 * k];
+          }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < nct) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (q + 16 * u < P) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) g[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][e], bv[k][u][e], g[k], 0, 0, 0);
+            }
+        }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) gsh[(fg * 4 + r) * C + c0 + fr] = g[r];
+    for (int k = 0; k < 4; ++k)
+      if (k < nct) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gsh[(fg * 4 + r) * C + wave * cw + 16 * k + fr] = g[k][r];
+      }
   }
   __syncthreads();
-  for (int r = 0; r < TI; ++r) {
-    const int i = i0 + r;
-    if (i >= P) break;
+  // normalisation backward, one wave per four rows (TI = 16 rows, 4 waves): the dot product is a wave reduction -- no block-wide
+  // barrier per row (16 x 2 barriers were a third of the launch)
+  static_assert(TI == 16, "four rows per wave");
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = wave * 4 + rr, i = i0 + r;
+    if (i >= P) break;                      // wave-uniform
     float dot = 0.f;
-    for (int c = threadIdx.x; c < C; c += 256) dot += tsh[r * C + c] * gsh[r * C + c];
-    dot = block_sum(dot, red);
+    for (int c = lane; c < C; c += 64) dot += tsh[r * C + c] * gsh[r * C + c];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, 64);
     const float nrm = w.tnorm[(int64_t)b * P + i];
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = lane; c < C; c += 64) {
       const float gg = gsh[r * C + c];
       w.dX[((int64_t)b * P + i) * C + c] = nrm > 1e-6f ? (gg - tsh[r * C + c] * dot) / nrm : gg / nrm;
     }
