@@ -301,6 +301,40 @@ __device__ __forceinline__ void pack_one_fp8(const gan_pack_desc& D, int lb) {
     *reinterpret_cast<uint32_t*>(dst + o) = f2e4m3x4(v[0], v[1], v[2], v[3]);
   }
 }
+// bf16 copies, the common case (every operand copy of the bf16 step): one thread per (row n, 8 consecutive channels, tap); the taps of a group are
+// neighbouring threads, so a wave's loads fall into a few source lines, and a thread's result leaves as ONE 16-byte store (8 consecutive kk share
+// a fragment lane).  The element-wise loop above stores 2 bytes at a time.
+__device__ __forceinline__ void pack_one_bf16x8(const gan_pack_desc& D, int lb) {
+  const float* __restrict__ src = D.src;
+  bf16_t* __restrict__ dst = reinterpret_cast<bf16_t*>(D.dst);
+  const int C8 = D.Cin >> 3;
+  const int64_t units = (int64_t)D.Nw * C8 * D.ntaps;
+  const int KB = D.ntaps * D.Cin / 32;
+  for (int64_t u = lb * (int64_t)blockDim.x + threadIdx.x; u < units; u += (int64_t)D.nblocks * blockDim.x) {
+    const int t = (int)(u % D.ntaps);                    // neighbouring threads: the taps of one (n, 8 channels) group -- they share its source lines
+    const int64_t r = u / D.ntaps;
+    const int c = (int)(r % C8) * 8, n = (int)(r / C8);
+    const int k = D.khw[t];
+    uint32_t pk[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      float v[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int ce = c + 2 * h + q;
+        const bool ok = k >= 0 && n < D.N_real && ce < D.C_real;
+        v[q] = ok ? src[(D.swap ? ((int64_t)ce * D.I2 + n) : ((int64_t)n * D.I2 + ce)) * D.KK + k] : 0.f;
+      }
+      pk[h] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    }
+    int64_t o = ((int64_t)n * D.ntaps + t) * D.Cin + c;
+    if (D.layout == 1) {
+      const int kk = t * D.Cin + c;
+      o = ((((int64_t)(n >> 4) * KB + (kk >> 5)) * 64) + ((kk & 31) >> 3) * 16 + (n & 15)) * 8;
+    }
+    *reinterpret_cast<u32x4_t*>(dst + o) = u32x4_t{pk[0], pk[1], pk[2], pk[3]};
+  }
+}
 __global__ __launch_bounds__(256) void pack_batch_kernel(const gan_pack_desc* __restrict__ d, int n) {
   int lo = 0, hi = n - 1;
   const int blk = blockIdx.x;
@@ -312,6 +346,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const gan_pack_desc* __
   const int lb = blk - D.first_block;
   if (lb >= D.nblocks) return;
   if (D.dtype == GAN_FP8) pack_one_fp8(D, lb);
+  else if (D.dtype == GAN_BF16 && (D.Cin & 7) == 0 && ((uintptr_t)D.dst & 15) == 0) pack_one_bf16x8(D, lb);
   else if (D.dtype == GAN_BF16) pack_one<bf16_t>(D, lb);
   else pack_one<float>(D, lb);
 }
