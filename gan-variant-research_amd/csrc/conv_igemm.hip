@@ -15,6 +15,7 @@
 //  * bf16 path: v_mfma_f32_16x16x32_bf16; fp32 (parity) path: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain);
 //  * block id -> tile mapping keeps all N-tiles of one M-tile on one XCD (shared A tile served from that L2).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -22,6 +23,7 @@ namespace {
 struct ConvArgs {
   const char* in; const char* w; const float* bias; char* out; const char* mask; const int32_t* tapoff; float* stats;
   int M, HoWo, Wo;
+  uint32_t wo_magic;   // ceil(2^32 / Wo): r / Wo == umulhi(r, wo_magic) for every pixel index r < HoWo of one image (host-checked)
   int Cin, lgCin, ntaps, Ktot, nk;
   int in_Hp, in_Wp, in_y0, in_x0, in_sy, in_sx;
   int out_Hp, out_Wp, out_C, out_y0, out_x0, out_sy, out_sx;
@@ -64,33 +66,61 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
   int32_t* taptab = reinterpret_cast<int32_t*>(lds + 2 * STAGE);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // XCD-aware tile mapping: blocks L and L+8 share an XCD; give them the same M-tile.
-  const int L = blockIdx.x, grp = L / (8 * a.NTILES), rem = L % (8 * a.NTILES);
-  const int ntile = rem >> 3, mtile = grp * 8 + (rem & 7);
-  if (mtile >= a.MT) return;
-  const int m0 = mtile * BM, n0 = ntile * BN;
+  // PERSISTENT blocks (round 3): a block walks virtual block ids L = blockIdx.x, + gridDim.x, ... and stages the first K-step of its next
+  // tile before the epilogue of the current one.  Measured on the 3x3 stride-2 64->128 layer (9 K-steps per tile, 32 images): 121 of the
+  // 199 us were prologue + first stage + epilogue of 4096 one-tile blocks (GAN_CONV_DEBUG=8); the MFMAs were 9 us of it.
+  // XCD-aware tile mapping: virtual blocks L and L+8 share an XCD (gridDim.x is a multiple of 8); give them the same M-tile.
+  const int nvirt = ((a.MT + 7) / 8) * 8 * a.NTILES;
+  auto decode = [&](int L, int& m0, int& n0) {
+    const int grp = L / (8 * a.NTILES), rem = L % (8 * a.NTILES);
+    const int ntile = rem >> 3, mtile = grp * 8 + (rem & 7);
+    m0 = mtile * BM; n0 = ntile * BN;
+    return mtile < a.MT;
+  };
+  auto next_valid = [&](int L, int& m0, int& n0) {      // first virtual id >= L of this block's sequence that is a real tile, or -1
+    for (; L < nvirt; L += gridDim.x)
+      if (decode(L, m0, n0)) return L;
+    return -1;
+  };
+  int m0, n0;
+  int L = next_valid(blockIdx.x, m0, n0);
+  if (L < 0) return;
 
   for (int i = tid; i < a.ntaps; i += NTHR) taptab[i] = a.tapoff[i];
 
   // ---- per-thread staging assignment: LDS position p of row r holds source chunk c = p ^ (r & 7)
   const int rr = tid >> 3, pp = tid & 7, cc = pp ^ (rr & 7);
   constexpr int RSTEP = NTHR / 8;  // rows covered per staging instruction of the block
-  uint32_t a_row[AI];
+  // pixel index -> (image, row, column) with ONE integer division per tile (of its first pixel; the rows of a tile are at most BM - 1
+  // further on): the 16 divisions per tile and lane of the first version were as many issue slots as the MFMAs of a 9-step tile
+  auto split = [&](int mbase, int bbase, int rbase, int m, int& b, int& ho, int& wo) {
+    int r = rbase + (m - mbase);
+    b = bbase;
+    if (a.HoWo >= BM) { if (r >= a.HoWo) { r -= a.HoWo; ++b; } }
+    else { const int q = r / a.HoWo; r -= q * a.HoWo; b += q; }        // maps smaller than a tile: several images per tile (rare, small)
+    ho = a.wo_magic ? (int)__umulhi((uint32_t)r, a.wo_magic) : r;      // magic 0: one-pixel-wide maps
+    wo = r - ho * a.Wo;
+  };
+  auto rows = [&](int m0, int n0, uint32_t (&a_row)[AI], uint32_t (&b_row)[BI]) {
+    const int b0 = m0 / a.HoWo, r0 = m0 - b0 * a.HoWo;
 #pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    int m = m0 + rr + RSTEP * i;
-    m = m < a.M ? m : a.M - 1;
-    int b = m / a.HoWo, r2 = m - b * a.HoWo, ho = r2 / a.Wo, wo = r2 - ho * a.Wo;
-    a_row[i] = (uint32_t)(((b * a.in_Hp + ho * a.in_sy + a.in_y0) * a.in_Wp + wo * a.in_sx + a.in_x0) * a.Cin) * (uint32_t)sizeof(T);
-  }
-  uint32_t b_row[BI];
+    for (int i = 0; i < AI; ++i) {
+      int m = m0 + rr + RSTEP * i;
+      m = m < a.M ? m : a.M - 1;
+      int b, ho, wo;
+      split(m0, b0, r0, m, b, ho, wo);
+      a_row[i] = (uint32_t)(((b * a.in_Hp + ho * a.in_sy + a.in_y0) * a.in_Wp + wo * a.in_sx + a.in_x0) * a.Cin) * (uint32_t)sizeof(T);
+    }
 #pragma unroll
-  for (int i = 0; i < BI; ++i) b_row[i] = (uint32_t)((n0 + rr + RSTEP * i) * a.Ktot + cc * EPC) * (uint32_t)sizeof(T);
+    for (int i = 0; i < BI; ++i) b_row[i] = (uint32_t)((n0 + rr + RSTEP * i) * a.Ktot + cc * EPC) * (uint32_t)sizeof(T);
+  };
+  uint32_t a_row[AI], b_row[BI];
+  rows(m0, n0, a_row, b_row);
   const uint32_t lds_thr = (uint32_t)(wave * 1024);  // lane*16 is added by the hardware
 
   __syncthreads();  // tap table visible
 
-  auto stage = [&](int ks, int buf) {
+  auto stage = [&](const uint32_t (&a_row)[AI], const uint32_t (&b_row)[BI], int ks, int buf) {
     char* sa = lds + buf * STAGE;
     char* sb = sa + BM * 128;
     const int kk = ks * BKE + cc * EPC;
@@ -109,11 +139,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
 
   const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 15, fg = lane >> 4;
-  f32x4_t acc[4][NT];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   // fragment byte offsets inside a stage (row & 7 == fr & 7 for every tile row this lane reads)
   const int sw = fr & 7;
@@ -124,68 +149,108 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
   for (int j = 0; j < NT; ++j) wb[j] = (uint32_t)(BM * 128 + (wn * NT * 16 + j * 16 + fr) * 128);
 
   const int nk = (a.dbg & 8) ? 1 : a.nk;  // dbg 8: prologue + one K-step + epilogue only
-  stage(0, 0);
-  for (int ks = 0; ks < nk; ++ks) {
-    __syncthreads();  // stage ks landed (vmcnt(0) + barrier); everyone is done reading the other buffer
-    if (ks + 1 < nk) stage(ks + 1, (ks + 1) & 1);
-    const char* sbuf = lds + (ks & 1) * STAGE;
-#pragma unroll
-    for (int kq = 0; kq < 2; ++kq) {
-      const uint32_t co = (uint32_t)(((fg + 4 * kq) ^ sw) << 4);
-      u32x4_t xf[4], wf[NT];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const u32x4_t*>(sbuf + xa[i] + co);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const u32x4_t*>(sbuf + wb[j] + co);
-      if (a.dbg & 4) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(xf[i]));
-#pragma unroll
-        for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(wf[j]));
-        continue;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) Mma<T>::run(wf[j], xf[i], acc[i][j]);
-    }
-  }
-
-  // ---- epilogue: lane holds, per tile, pixel m = ..+fr and channels n = ..+fg*4 .. +3
   T* out = reinterpret_cast<T*>(a.out);
   const T* mask = reinterpret_cast<const T*>(a.mask);
+  int buf = 0;
+  stage(a_row, b_row, 0, 0);
+  while (true) {
+    // the tile after this one (its staging rows are computed while this tile's first stage is in flight)
+    int m0n, n0n;
+    const int Ln = next_valid(L + gridDim.x, m0n, n0n);
+    uint32_t a_rown[AI], b_rown[BI];
+    if (Ln >= 0) rows(m0n, n0n, a_rown, b_rown);
+
+    f32x4_t acc[4][NT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + fr;
-    if (m >= a.M) continue;
-    const int b = m / a.HoWo, r2 = m - b * a.HoWo, ho = r2 / a.Wo, wo = r2 - ho * a.Wo;
-    const int64_t ob = ((int64_t)(b * a.out_Hp + ho * a.out_sy + a.out_y0) * a.out_Wp + wo * a.out_sx + a.out_x0) * a.out_C;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + wn * NT * 16 + j * 16 + fg * 4;
-      if (n >= a.Nst) continue;
-      float v[4];
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int ks = 0; ks < nk; ++ks) {
+      __syncthreads();  // stage ks landed (vmcnt(0) + barrier); everyone is done reading the other buffer
+      if (ks + 1 < nk) stage(a_row, b_row, ks + 1, buf ^ 1);
+      else if (Ln >= 0) stage(a_rown, b_rown, 0, buf ^ 1);     // the next tile's first stage rides under this tile's last K-step and epilogue
+      const char* sbuf = lds + buf * STAGE;
+      buf ^= 1;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t = acc[i][j][e];
-        if (a.bias) t += a.bias[n + e];
-        v[e] = act_apply(t, a.act);
-      }
-      if (mask) {
-        const int64_t mb = ((int64_t)(b * a.mask_Hp + ho * a.out_sy + a.mask_y0) * a.mask_Wp + wo * a.out_sx + a.mask_x0) * a.out_C;
+      for (int kq = 0; kq < 2; ++kq) {
+        const uint32_t co = (uint32_t)(((fg + 4 * kq) ^ sw) << 4);
+        u32x4_t xf[4], wf[NT];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= (ld1<T>(mask + mb + n + e) > 0.f ? 1.f : 0.2f);
-      }
-      if (a.dbg & 16) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
-      if constexpr (sizeof(T) == 4) {
-        *reinterpret_cast<f32x4_t*>(out + ob + n) = f32x4_t{v[0], v[1], v[2], v[3]};
-      } else {
-        u32x2_t pk;
-        pk[0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        pk[1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        *reinterpret_cast<u32x2_t*>(out + ob + n) = pk;
+        for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const u32x4_t*>(sbuf + xa[i] + co);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const u32x4_t*>(sbuf + wb[j] + co);
+        if (a.dbg & 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(xf[i]));
+#pragma unroll
+          for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(wf[j]));
+          continue;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) Mma<T>::run(wf[j], xf[i], acc[i][j]);
       }
     }
+
+    // ---- epilogue: lane holds, per tile, pixel m = ..+fr and channels n = ..+fg*4 .. +3.  One bias quad per channel tile (not per value),
+    // the activation switch outside the value loops, one division per tile
+    {
+      const int eb0 = m0 / a.HoWo, er0 = m0 - eb0 * a.HoWo;
+      f32x4_t bq[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * NT * 16 + j * 16 + fg * 4;
+        bq[j] = (a.bias && n < a.Nst) ? *reinterpret_cast<const f32x4_t*>(a.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+      auto body = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = m0 + wm * 64 + i * 16 + fr;
+          if (m >= a.M) continue;
+          int b, ho, wo;
+          split(m0, eb0, er0, m, b, ho, wo);
+          const int64_t ob = ((int64_t)(b * a.out_Hp + ho * a.out_sy + a.out_y0) * a.out_Wp + wo * a.out_sx + a.out_x0) * a.out_C;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wn * NT * 16 + j * 16 + fg * 4;
+            if (n >= a.Nst) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float t = acc[i][j][e] + bq[j][e];
+              v[e] = ACT == GAN_ACT_RELU ? fmaxf(t, 0.f) : ACT == GAN_ACT_LRELU ? (t > 0.f ? t : 0.2f * t) : ACT == GAN_ACT_TANH ? tanhf(t) : t;
+            }
+            if (mask) {
+              const int64_t mb = ((int64_t)(b * a.mask_Hp + ho * a.out_sy + a.mask_y0) * a.mask_Wp + wo * a.out_sx + a.mask_x0) * a.out_C;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= (ld1<T>(mask + mb + n + e) > 0.f ? 1.f : 0.2f);
+            }
+            if (a.dbg & 16) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
+            if constexpr (sizeof(T) == 4) {
+              *reinterpret_cast<f32x4_t*>(out + ob + n) = f32x4_t{v[0], v[1], v[2], v[3]};
+            } else {
+              u32x2_t pk;
+              pk[0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+              pk[1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+              *reinterpret_cast<u32x2_t*>(out + ob + n) = pk;
+            }
+          }
+        }
+      };
+      if (a.act == GAN_ACT_NONE) body(std::integral_constant<int, GAN_ACT_NONE>{});
+      else if (a.act == GAN_ACT_RELU) body(std::integral_constant<int, GAN_ACT_RELU>{});
+      else if (a.act == GAN_ACT_LRELU) body(std::integral_constant<int, GAN_ACT_LRELU>{});
+      else body(std::integral_constant<int, GAN_ACT_TANH>{});
+    }
+    if (Ln < 0) break;
+    L = Ln; m0 = m0n; n0 = n0n;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) a_row[i] = a_rown[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) b_row[i] = b_rown[i];
   }
 }
 
@@ -195,7 +260,10 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
   ConvArgs k = a;
   k.MT = (a.M + BM - 1) / BM;
   k.NTILES = (a.Nst + BN - 1) / BN;
-  const int grid = ((k.MT + 7) / 8) * 8 * k.NTILES;
+  const int nvirt = ((k.MT + 7) / 8) * 8 * k.NTILES;
+  // persistent: as many blocks as the chip holds at once (LDS: two 2 x 32 KB blocks per CU on 256 CUs), a multiple of 8 (XCD mapping)
+  static const int resident = [] { const char* e = getenv("GAN_IGEMM_BLOCKS"); const int v = e ? atoi(e) : 512; return v >= 8 ? (v / 8) * 8 : 512; }();
+  const int grid = nvirt < resident ? nvirt : resident;
   hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, NT>), dim3(grid), dim3(WM * WN * 64), 0, s, k);
   GAN_LAUNCH_CHECK();
   return 0;
@@ -237,6 +305,9 @@ extern "C" int gan_conv_igemm(const gan_conv_desc* d, void* stream) {
   a.in = (const char*)d->in; a.w = (const char*)d->w; a.bias = d->bias; a.out = (char*)d->out; a.mask = (const char*)d->mask;
   a.tapoff = d->tapoff; a.stats = d->stats;
   a.M = (int)M; a.HoWo = d->Ho * d->Wo; a.Wo = d->Wo;
+  // r / Wo by multiplication: with magic = ceil(2^32 / Wo) the quotient is exact while r * Wo < 2^32; r < Ho * Wo (+ one tile)
+  GAN_CHECK((int64_t)(a.HoWo + 256) * d->Wo < (1ll << 32), "conv: map too large for the index arithmetic");
+  a.wo_magic = d->Wo == 1 ? 0u : (uint32_t)(((1ull << 32) + d->Wo - 1) / d->Wo);
   a.Cin = d->Cin; a.lgCin = __builtin_ctz(d->Cin); a.ntaps = d->ntaps; a.Ktot = d->ntaps * d->Cin; a.nk = a.Ktot / bke;
   a.in_Hp = d->in_Hp; a.in_Wp = d->in_Wp; a.in_y0 = d->in_y0; a.in_x0 = d->in_x0; a.in_sy = d->in_sy; a.in_sx = d->in_sx;
   a.out_Hp = d->out_Hp; a.out_Wp = d->out_Wp; a.out_C = d->out_C; a.out_y0 = d->out_y0; a.out_x0 = d->out_x0;

@@ -872,7 +872,7 @@ extern "C" int gan_conv_patch_ok(const gan_conv_desc* d) {
   const int slots = fp8 ? d->Cin / 2 : d->Cin;             // 2-byte slots per pixel (fp8: two channels per slot)
   if ((d->dtype != GAN_BF16 && !fp8) || slots < 64 || slots % 64 != 0 || d->Nw % BN != 0 || d->Nst % 8 != 0 || d->out_C % 8 != 0) return 0;
   if (fp8 && (d->mask || !d->w_scale || patch_span(d, 256) > RMAX_WIDE)) return 0;   // fp8: 256-row tile, plain epilogue
-  if (d->max_tapoff <= 0 || d->ntaps < 1) return 0;
+  if (d->max_tapoff <= 0 || d->ntaps < 1 || d->Wo < 2) return 0;     // one-pixel-wide maps: m / Wo has no 32-bit magic (umulhi(m, 2^32 - 1) = m - 1)
   // 32-bit byte offsets into the input, output and mask tensors
   const int64_t lim = (1ll << 32) - 4096;
   if ((int64_t)d->B * d->in_Hp * d->in_Wp * d->Cin * 2 >= lim || (int64_t)d->B * d->out_Hp * d->out_Wp * d->out_C * 2 >= lim ||
@@ -930,7 +930,7 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   a.in = (const char*)d->in; a.w = (const char*)d->w; a.bias = d->bias; a.out = (char*)d->out; a.mask = (const char*)d->mask; a.tapoff = d->tapoff;
   // m / Wo by multiplication: with magic = ceil(2^32 / Wo) the quotient is exact while m * (magic * Wo - 2^32) < 2^32, i.e. for m * Wo < 2^32
   if ((int64_t)(M_img + 288) * d->Wo >= (1ll << 32) || d->Wo < 1) return gan_set_error(-1, "conv_patch: map too large for the index arithmetic");
-  a.wo_magic = d->Wo == 1 ? 0xffffffffu : (uint32_t)(((1ull << 32) + d->Wo - 1) / d->Wo);
+  a.wo_magic = (uint32_t)(((1ull << 32) + d->Wo - 1) / d->Wo);      // Wo >= 2 (gan_conv_patch_ok): for Wo = 1 no 32-bit magic exists
   a.B = d->B; a.M_img = M_img; a.Wo = d->Wo; a.MT_img = (M_img + BM - 1) / BM; a.NTILES = (d->Nst + BN - 1) / BN;
   a.tiles = a.B * a.MT_img * a.NTILES;
   const bool fp8 = d->dtype == GAN_FP8;
