@@ -19,6 +19,7 @@ struct WgArgs {
   int x_Hp, x_Wp, x_y0, x_x0, x_sy, x_sx;
   int g_Hp, g_Wp, g_C, g_y0, g_x0, g_sy, g_sx;
   int JTILES, NTILES;
+  int fast;   // every 64-pixel stage lies inside one image and starts at a fixed position of its image rows: uniform stage base + per-thread constants
 };
 
 __device__ __forceinline__ void glds16w(const char* gbase, uint32_t goff, char* lds) {
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
   constexpr int GTHR = KM * GCH;  // chunks per stage
   constexpr int GI = (GTHR + 255) / 256;
   const int gr = tid / GCH, gp = tid % GCH;
+  constexpr int GRSTEP = 256 / GCH;  // rows covered by one staging instruction of the block for g
   const int gq = (GCH == 16) ? (gp ^ swz_h(gr)) : gp;
   int gn = n0 + gq * EPC;
   if (gn >= a.N) gn = 0;  // clamp to a valid chunk; those output rows are never stored
@@ -81,11 +83,42 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
   int xb, xho, xwo, gb, gho, gwo;
   decomp(m_begin + xr, xb, xho, xwo);
   decomp(m_begin + gr, gb, gho, gwo);
-  constexpr int GRSTEP = 256 / GCH;  // rows covered by one staging instruction of the block for g
 
+  // FAST addressing (a.fast: HoWo % 64 == 0 and Wo a multiple or a divisor of 64 -- every map of the 256^2 / 512^2 networks): a stage's 64
+  // pixels lie inside one image at the same place of its rows for every stage, so a thread's row is the wave-UNIFORM position of the
+  // stage (scalar registers, stepped by 64 pixels) plus an offset that never changes.  The general path below re-derives (image, row,
+  // column) of 4 + GI rows per stage with wrap loops: as many vector instructions as the stage's 32 MFMAs take cycles.
+  uint32_t xoff[4], goff[GI];
+  int sb = 0, sho = 0, swo = 0;      // uniform: position of the next stage to be issued
+  if (a.fast) {
+    auto rel = [&](int rho, int sy, int sx, int Wp, int C) {
+      const int dho = a.Wo >= KM ? 0 : rho / a.Wo, dwo = rho - dho * a.Wo;
+      return (uint32_t)((dho * sy * Wp + dwo * sx) * C) * (uint32_t)sizeof(T);
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xoff[i] = rel(xr + 16 * i, a.x_sy, a.x_sx, a.x_Wp, a.Cx);
+#pragma unroll
+    for (int i = 0; i < GI; ++i) goff[i] = rel(gr + GRSTEP * i, a.g_sy, a.g_sx, a.g_Wp, a.g_C);
+    sb = m_begin / a.HoWo;
+    const int r = m_begin - sb * a.HoWo;
+    sho = r / a.Wo; swo = r - sho * a.Wo;
+  }
   auto stage = [&](int ks, int buf) {
     char* sx = lds + buf * STAGE;
     char* sg = sx + KM * XROWB;
+    if (a.fast) {
+      const uint32_t xbase = (uint32_t)(((sb * a.x_Hp + sho * a.x_sy + a.x_y0) * a.x_Wp + swo * a.x_sx + a.x_x0) * a.Cx) * (uint32_t)sizeof(T);
+      const uint32_t gbase = (uint32_t)(((sb * a.g_Hp + sho * a.g_sy + a.g_y0) * a.g_Wp + swo * a.g_sx + a.g_x0) * a.g_C) * (uint32_t)sizeof(T);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) glds16w(a.x, xbase + xoff[i] + xk, sx + wave * 1024 + i * 4096);
+#pragma unroll
+      for (int i = 0; i < GI; ++i)
+        if (GTHR >= 256 || tid < GTHR) glds16w(a.g, gbase + goff[i] + gk, sg + wave * 1024 + i * 4096);
+      swo += KM;
+      while (swo >= a.Wo) { swo -= a.Wo; ++sho; }
+      while (sho >= a.Ho) { sho -= a.Ho; ++sb; }
+      return;
+    }
     int b = xb, ho = xho, wo = xwo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -426,6 +459,8 @@ extern "C" int gan_conv_wgrad(const gan_wgrad_desc* d, void* stream) {
   a.Cx = d->Cx; a.lgCx = __builtin_ctz(d->Cx); a.ntaps = d->ntaps; a.Ktot = d->ntaps * d->Cx; a.N = d->N;
   a.x_Hp = d->x_Hp; a.x_Wp = d->x_Wp; a.x_y0 = d->x_y0; a.x_x0 = d->x_x0; a.x_sy = d->x_sy; a.x_sx = d->x_sx;
   a.g_Hp = d->g_Hp; a.g_Wp = d->g_Wp; a.g_C = d->g_C; a.g_y0 = d->g_y0; a.g_x0 = d->g_x0; a.g_sy = d->g_sy; a.g_sx = d->g_sx;
+  static const bool no_fast = [] { const char* e = getenv("GAN_WGRAD_SLOW_ADDR"); return e && atoi(e); }();     // A/B switch
+  a.fast = (!no_fast && a.HoWo % 64 == 0 && (a.Wo % 64 == 0 || 64 % a.Wo == 0)) ? 1 : 0;
   const int JT = 16 * epc;
   a.JTILES = (a.Ktot + JT - 1) / JT;
   hipStream_t s = (hipStream_t)stream;
