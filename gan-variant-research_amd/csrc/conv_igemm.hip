@@ -213,9 +213,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
           int b, ho, wo;
           split(m0, eb0, er0, m, b, ho, wo);
           const int64_t ob = ((int64_t)(b * a.out_Hp + ho * a.out_sy + a.out_y0) * a.out_Wp + wo * a.out_sx + a.out_x0) * a.out_C;
+          // bf16, Nst % 8 == 0: lanes 16 apart hold the same pixel and adjacent channel quads; of each pair of channel tiles even fg keeps
+          // the first and odd fg the second (v_permlane16_swap, as in conv_patch.hip) -> one 16-byte store per lane and tile pair instead of
+          // two 8-byte ones (the 8-byte stores of the 3x3 s2 64->128 layer were 43 of its 135 us)
+          const bool vec16 = sizeof(T) == 2 && NT % 2 == 0 && (a.Nst & 7) == 0 && (a.out_C & 7) == 0 && !(a.dbg & 16);
+          u32x2_t pkv[NT];
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             const int n = n0 + wn * NT * 16 + j * 16 + fg * 4;
+            pkv[j] = u32x2_t{0, 0};
             if (n >= a.Nst) continue;
             float v[4];
 #pragma unroll
@@ -232,10 +238,20 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
             if constexpr (sizeof(T) == 4) {
               *reinterpret_cast<f32x4_t*>(out + ob + n) = f32x4_t{v[0], v[1], v[2], v[3]};
             } else {
-              u32x2_t pk;
-              pk[0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-              pk[1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-              *reinterpret_cast<u32x2_t*>(out + ob + n) = pk;
+              pkv[j][0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+              pkv[j][1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+              if (!vec16) *reinterpret_cast<u32x2_t*>(out + ob + n) = pkv[j];
+            }
+          }
+          if constexpr (sizeof(T) == 2 && NT % 2 == 0) {
+            if (vec16) {
+#pragma unroll
+              for (int jp = 0; jp < NT / 2; ++jp) {
+                const auto ra = __builtin_amdgcn_permlane16_swap(pkv[2 * jp][0], pkv[2 * jp + 1][0], false, false);
+                const auto rb = __builtin_amdgcn_permlane16_swap(pkv[2 * jp][1], pkv[2 * jp + 1][1], false, false);
+                const int nst = n0 + wn * NT * 16 + (2 * jp + (fg & 1)) * 16 + (fg & 2) * 4;
+                if (nst < a.Nst) *reinterpret_cast<u32x4_t*>(out + ob + nst) = u32x4_t{ra[0], rb[0], ra[1], rb[1]};
+              }
             }
           }
         }
