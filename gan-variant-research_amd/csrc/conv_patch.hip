@@ -240,7 +240,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
         }
     };
     if constexpr (NT > 0) {
-      constexpr bool PRE = FI <= 4;
+      constexpr bool PRE = FI <= 4 && NT <= 9;       // 16 taps x 4 fragment addresses would be 64 registers
       uint32_t xa[PRE ? NT : 1][FI];
       if constexpr (PRE) {
 #pragma unroll
@@ -259,7 +259,15 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
         const TileGeo gs = last_chunk ? gn : g;
         const int cs = last_chunk ? 0 : c + 1;
         const char* pb = pbuf + PC * PATCHB;
-        u32x4_t stg = {0, 0, 0, 0};
+        // slices of the next slab moved per tap: a tap writes what the previous tap fetched and fetches its own share, so that the last tap's
+        // writes complete the slab (few-tap layers -- the sub-pixel phases have 1, 2 or 4 taps -- move several slices per tap; one-tap layers
+        // flush after the tap).  The tap loop stays branch-free in its loads: hipcc's s_waitcnt insertion turns conservative at every
+        // control-flow join (vmcnt(0): every k-step of the generic loop waits for the slab loads it has just issued -- 1.4-1.7 k cycles
+        // per k-step of 0.5 k cycles of MFMAs on the 4-tap phase launches)
+        constexpr int SP = NT > 1 ? (NSLICE + NT - 2) / (NT - 1) : NSLICE;
+        u32x4_t stg[SP];
+#pragma unroll
+        for (int u = 0; u < SP; ++u) stg[u] = u32x4_t{0, 0, 0, 0};
         // hipcc hoists loop-invariant per-lane addresses out of the (unrolled) loops and then spills them: the values that
         // feed the address arithmetic are made opaque where they are used
         auto x_load = [&](int t, int kq, u32x4_t (&xf)[FI]) {
@@ -288,8 +296,11 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
           w_load(g.n0, kb_cur + 1, Wb);
           x_load(t, 1, Xb);
           if (stage_next) {
-            if (t >= 1 && t <= NSLICE) slab_store(PC ^ 1, t - 1, stg);
-            if (t < NSLICE) stg = slab_load(gs, cs, t);
+#pragma unroll
+            for (int u = 0; u < SP; ++u) {
+              if (t >= 1 && (t - 1) * SP + u < NSLICE) slab_store(PC ^ 1, (t - 1) * SP + u, stg[u]);
+              if (t * SP + u < NSLICE) stg[u] = slab_load(gs, cs, t * SP + u);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
           mma_part(Wa, Xa, FI / 4, FI);
@@ -305,7 +316,13 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
           __builtin_amdgcn_sched_barrier(0);
           mma_part(Wb, Xb, FI / 4, FI);
         }
-        static_assert(NT > NSLICE, "the static schedule stages one slice per tap");
+        if constexpr ((NT - 1) * SP < NSLICE) {      // one-tap layers: what the only tap fetched is written after it (an exposed round trip)
+          if (stage_next) {
+#pragma unroll
+            for (int u = 0; u < SP; ++u)
+              if ((NT - 1) * SP + u < NSLICE) slab_store(PC ^ 1, (NT - 1) * SP + u, stg[u]);
+          }
+        }
         __syncthreads();   // every wave is done with this slab; the other buffer is completely written
         stamp();
       };
@@ -915,8 +932,12 @@ static int patch_variant(const gan_conv_desc* d) {
   const int slots = fp8 ? d->Cin / 2 : d->Cin;
   const bool wide = BM == 256 && patch_span(d, 256) > RMAX;      // needs the 9-slice buffers (maps wider than 64 pixels)
   const bool chain = d->stats_mode != 0;      // backward-chain epilogue: generic tap loop
-  const bool st9 = !fp8 && !chain && BN == 128 && BM == 256 && !wide && d->ntaps == 9 && (slots / 64) % 2 == 0 && !static_off;
-  return BM | (BN << 12) | ((wide ? 9 : 7) << 24) | ((fp8 ? 1 : 0) << 28) | ((st9 ? 1 : 0) << 29);
+  const bool st_ok = !fp8 && !chain && BN == 128 && BM == 256 && (slots / 64) % 2 == 0 && !static_off;
+  const bool st9 = st_ok && !wide && d->ntaps == 9;
+  // static schedules for the other tap counts of the two networks (bits 30-31: 1 = 4 taps, 2 = 2 taps, 3 = 16 taps): the sub-pixel phases of the
+  // transposed convolutions / strided input gradients (2 and 4 taps, also on the 9-slice buffers) and the discriminator's 4x4 windows
+  const int stx = !st_ok ? 0 : d->ntaps == 4 ? 1 : d->ntaps == 2 ? 2 : (d->ntaps == 16 && !wide) ? 3 : 0;
+  return BM | (BN << 12) | ((wide ? 9 : 7) << 24) | ((fp8 ? 1 : 0) << 28) | ((st9 ? 1 : 0) << 29) | (stx << 30);
 }
 extern "C" int gan_conv_patch_variant(const gan_conv_desc* d) { return gan_conv_patch_ok(d) ? patch_variant(d) : 0; }
 
@@ -982,6 +1003,9 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
     auto raise = [](const void* f, int bytes) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; };
     if (!raise((const void*)conv_patch_kernel<256, 2, 0>, lds_bytes(7)) || !raise((const void*)conv_patch_kernel<288, 4, 0>, lds_bytes(7)) ||
         !raise((const void*)conv_patch_kernel<256, 2, 9>, lds_bytes(7)) || !raise((const void*)conv_patch_fp8_kernel, lds_bytes(7)) ||
+        !raise((const void*)conv_patch_kernel<256, 2, 4>, lds_bytes(7)) || !raise((const void*)conv_patch_kernel<256, 2, 2>, lds_bytes(7)) ||
+        !raise((const void*)conv_patch_kernel<256, 2, 16>, lds_bytes(7)) || !raise((const void*)conv_patch_kernel<256, 2, 4, false, 9>, lds_bytes(9)) ||
+        !raise((const void*)conv_patch_kernel<256, 2, 2, false, 9>, lds_bytes(9)) ||
         !raise((const void*)conv_patch_kernel<256, 2, 0, false, 9>, lds_bytes(9)) || !raise((const void*)conv_patch_fp8_wide_kernel, lds_bytes(9)) ||
         !raise((const void*)conv_patch_kernel<256, 4, 0, false, 7, 256>, lds_bytes(7)) || !raise((const void*)conv_patch_kernel<288, 4, 0, false, 7, 256>, lds_bytes(7)) ||
         !raise((const void*)conv_patch_kernel<256, 4, 0, false, 9, 256>, lds_bytes(9)) ||
@@ -995,6 +1019,7 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
   // stream clocks lower (2.04 -> 1.88 GHz), so the forward gains 3 % wall (69.5 -> 67.2 us = 1.15 PFLOP/s); on the 288-row tile,
   // whose 9 fragment addresses per tap do not fit in registers, it lost 9 % and is not instantiated.
   const bool wide = ((variant >> 24) & 0xf) == 9, st9 = (variant >> 29) & 1;
+  const int stx = (variant >> 30) & 3;
   if (a.smode != 0) {
     if (BN == 256) {
       if (BM == 256 && wide) hipLaunchKernelGGL((conv_patch_bwdchain_kernel<256, 4, 9, 256>), dim3(grid), dim3(NTHR), lds_bytes(9), s, a);
@@ -1014,7 +1039,12 @@ int gan_conv_patch_launch(const gan_conv_desc* d, hipStream_t s) {
     else if (BM == 256) hipLaunchKernelGGL((conv_patch_kernel<256, 4, 0, false, 7, 256>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<288, 4, 0, false, 7, 256>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
   } else if (BM == 256) {
-    if (wide) hipLaunchKernelGGL((conv_patch_kernel<256, 2, 0, false, 9>), dim3(grid), dim3(NTHR), lds_bytes(9), s, a);
+    if (stx == 1 && wide) hipLaunchKernelGGL((conv_patch_kernel<256, 2, 4, false, 9>), dim3(grid), dim3(NTHR), lds_bytes(9), s, a);
+    else if (stx == 2 && wide) hipLaunchKernelGGL((conv_patch_kernel<256, 2, 2, false, 9>), dim3(grid), dim3(NTHR), lds_bytes(9), s, a);
+    else if (stx == 1) hipLaunchKernelGGL((conv_patch_kernel<256, 2, 4>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
+    else if (stx == 2) hipLaunchKernelGGL((conv_patch_kernel<256, 2, 2>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
+    else if (stx == 3) hipLaunchKernelGGL((conv_patch_kernel<256, 2, 16>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
+    else if (wide) hipLaunchKernelGGL((conv_patch_kernel<256, 2, 0, false, 9>), dim3(grid), dim3(NTHR), lds_bytes(9), s, a);
     else if (st9) hipLaunchKernelGGL((conv_patch_kernel<256, 2, 9>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<256, 2, 0>), dim3(grid), dim3(NTHR), lds_bytes(7), s, a);
   } else {

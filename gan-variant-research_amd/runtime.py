@@ -307,10 +307,11 @@ class HipOps:
         return int(self.lib.gan_conv_patch_tile_cols(C.byref(self._conv_desc(c))))
 
     def conv_patch_variant(self, c: ConvCall) -> dict:
-        """The range-patch instantiation this call runs on ({} if it does not qualify): rows, cols, slices, fp8, static9."""
+        """The range-patch instantiation this call runs on ({} if it does not qualify): rows, cols, slices, fp8, static9, static_taps."""
         d = self._conv_desc(c)
         v = int(self.lib.gan_conv_patch_variant(C.byref(d))) if c.w_frag else 0
-        return {} if v == 0 else {"rows": v & 0xfff, "cols": (v >> 12) & 0xfff, "slices": (v >> 24) & 0xf, "fp8": bool((v >> 28) & 1), "static9": bool((v >> 29) & 1)}
+        return {} if v == 0 else {"rows": v & 0xfff, "cols": (v >> 12) & 0xfff, "slices": (v >> 24) & 0xf, "fp8": bool((v >> 28) & 1), "static9": bool((v >> 29) & 1),
+                                      "static_taps": 9 if (v >> 29) & 1 else (0, 4, 2, 16)[(v >> 30) & 3]}
 
     def conv_win7_ok(self, c: ConvCall, ty0: int, tx0: int) -> bool:
         """True if the 7x7 window kernel takes this call with its 49 row-major taps starting at (ty0, tx0)."""

@@ -536,7 +536,7 @@ def test_fp8_conv_path_wide_maps_hip():
     got, gotd = cases.run_conv_fp8(ctx, B=1, H=128, with_stats=True, info=info)
     for which in ("fwd", "dgrad"):
         v = ctx.ops.conv_patch_variant(info[which])
-        assert v == {"rows": 256, "cols": 128, "slices": 9, "fp8": True, "static9": False}, (which, v)
+        assert v == {"rows": 256, "cols": 128, "slices": 9, "fp8": True, "static9": False, "static_taps": 0}, (which, v)
     emu, emud = cases.run_conv_fp8(Ctx(EmuOps(), "cpu", BF16), B=1, H=128)
     rms, rmsd = float(emu.pow(2).mean().sqrt()), emud.pow(2).mean((1, 2, 3)).sqrt()
     # 4.2 M outputs: some sit on a bf16 rounding boundary, where the two fp32 summation orders land one output ulp (<= 2^-7 |v|) apart

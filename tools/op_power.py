@@ -13,6 +13,10 @@ import time
 os.environ.setdefault("GAN_SINGLE_STREAM", "1")
 import torch
 
+if os.environ.get("GAN_W0"):       # diagnostic: every range-patch weight fetch reads fragment block 0 (L1-resident; results wrong)
+    _stamp_buf = torch.zeros(256 * 32, dtype=torch.int64, device="cuda:0")
+    os.environ["GAN_PATCH_STAMPS"] = str(_stamp_buf.data_ptr() | 2)
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from gan_variant_research_amd import cut as C  # noqa: E402
