@@ -299,7 +299,8 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs& a) {
 #pragma unroll
             for (int u = 0; u < SP; ++u) {
               if (t >= 1 && (t - 1) * SP + u < NSLICE) slab_store(PC ^ 1, (t - 1) * SP + u, stg[u]);
-              if (t * SP + u < NSLICE) stg[u] = slab_load(gs, cs, t * SP + u);
+              // slices past the tile's span are never read: re-read slice 0 instead (an L1 / L2 hit) -- these launches are bound by the bytes they stage
+              if (t * SP + u < NSLICE) stg[u] = slab_load(gs, cs, t * SP + u < a.nslice ? t * SP + u : 0);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
