@@ -32,6 +32,49 @@ def test_conv_geometry_hip_tile288(geom, monkeypatch):
 
 
 WIDE_MAP_256 = (256, 256, 3, 1, 1, False, 128, True)     # a residual layer of a 512x512 image: 9-slice buffers (256-row tile only)
+# sub-pixel phases on a 256-pixel-wide map (the second up-sampling layer of a 512x512 image): the 2- and 4-tap static schedules on the 9-slice
+# buffers (a 256-pixel tile plus one row and one pixel spans 515 pixels; at 128 pixels width it fits the 7-slice buffers)
+WIDE_PHASES = [(128, 64, 3, 2, 1, True, 256, False),      # paired x-phases: 2 taps in a row (7 slices) and 4 taps (9 slices)
+               (256, 128, 3, 2, 1, True, 256, False)]     # unpaired phases: the 2-tap phase with a vertical tap spans 514 pixels (9 slices)
+
+
+def _static_taps_of(ctx, geom, B):
+    """Plans forward and input gradient of one geometry (no launch) and returns the static tap schedules the planner chose."""
+    from gan_variant_research_amd.convplan import ConvLayer
+    cin, cout, k, s, p, tr, H, reflect = geom
+    w = torch.zeros((cin, cout, k, k) if tr else (cout, cin, k, k), device=DEV)
+    layer = ConvLayer(ctx, w, torch.zeros(cout, device=DEV), torch.zeros_like(w), torch.zeros(cout, device=DEV), k, s, p, tr)
+    Ho = 2 * H if tr else (H + 2 * p - k) // s + 1
+    x = ctx.view(B, H, H, cases.cpad(cin), max(p, 1))
+    y = ctx.view(B, Ho, Ho, cases.cpad(cout), 0)
+    ops = list(layer.fwd(x, y))
+    if tr or s == 2:
+        ops += layer.dgrad(ctx.view(B, Ho, Ho, cases.cpad(cout), 1), ctx.view(B, H, H, cases.cpad(cin), 0))
+    out = set()
+    for op in ops:
+        c = getattr(op, "conv", None)
+        if c is not None and c.w_frag:
+            v = ctx.ops.conv_patch_variant(c)
+            out.add((v.get("static_taps", 0), v.get("slices")))
+    return out
+
+
+def test_static_tap_schedules_are_reached_and_correct():
+    """The branch-free tap schedules for 2, 4 and 16 taps (conv_patch_kernel<256, 2, NT>): the geometries of cases.GEOMS that the parity
+    tests above run (transposed 256->128 / 128->64 layers, the 4x4 256->512 layer) really plan them, and the 9-slice instantiations
+    (256-pixel-wide maps: 512x512 images) are run against F.conv_transpose2d here."""
+    ctx = hip_ctx(BF16)
+    seen = set()
+    for geom in [g for g in cases.GEOMS if g[0] >= 128 and (g[5] or g[2] == 4)]:
+        seen |= _static_taps_of(ctx, geom, 3)
+    assert {(2, 7), (4, 7), (16, 7)} <= seen, seen
+    wide = set()
+    for geom in WIDE_PHASES:
+        wide |= _static_taps_of(ctx, geom, 1)
+    assert {(2, 9), (4, 9)} <= wide, wide
+    for geom in WIDE_PHASES:
+        cases.run_conv_geometry(ctx, geom, BF16, B=1)
+
 
 
 @pytest.mark.parametrize("bm", ["256", "288"])
