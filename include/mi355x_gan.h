@@ -129,8 +129,9 @@ int gan_conv_patch_tile_rows(const gan_conv_desc* d);
  * time) forces one wherever the layer is eligible; 0 if the descriptor does not qualify for the range-patch kernel */
 int gan_conv_patch_tile_cols(const gan_conv_desc* d);
 /* the instantiation gan_conv_igemm runs a qualifying descriptor on (0: it does not qualify): tile rows | tile columns << 12 | LDS
- * slices (7: maps up to 64 pixels wide, 9: up to 128) << 24 | e4m3 operands << 28 | static 3x3 schedule << 29.  Pure host-side query:
- * tests assert with it that a case really reaches the kernel it is meant to cover. */
+ * slices (7 or 9: pixels a tile's taps span, / 64) << 24 | e4m3 operands << 28 | static 3x3 schedule << 29 | other static tap
+ * schedules << 30 (1: 4 taps, 2: 2 taps, 3: 16 taps -- the sub-pixel phases and the discriminator's 4x4 windows).  The value uses bit 31:
+ * read it as unsigned.  Pure host-side query: tests assert with it that a case really reaches the kernel it is meant to cover. */
 int gan_conv_patch_variant(const gan_conv_desc* d);
 /* 1 if the descriptor qualifies for a 7x7 window kernel (bf16, stride 1, 49 row-major taps located by win_ty0/win_tx0, act none or
  * tanh, no mask / stats): Cin = 64, Nw = 16, Nst = out_C = 8 (the 64 -> 3 channel layers) or Cin = 8, Nw = Nst = out_C = 64 with the
