@@ -395,6 +395,16 @@ def test_cut_train_step_bf16_vs_oracle_at_benchmark_resolution(monkeypatch):
     assert float((img - ref_img).abs().max()) < 5e-2
 
 
+@pytest.mark.parametrize("B,S", [(1, 64), (3, 64), (5, 64), (2, 80), (3, 96)])
+def test_cut_train_step_ragged_shapes_vs_oracle(B, S):
+    """Batch sizes that are not powers of two (and a single image) and image sizes whose maps are no multiple of any tile (80 -> 20x20 and
+    40x40 maps, 96 -> 24x24): GEMM row counts with tails in every tile size (128, 256, 288), persistent blocks with uneven tile counts,
+    weight-gradient stages that straddle image rows and images (the general addressing path), split-K over 2B = 2 ... 10 images -- fp32
+    mode against the oracle within 1e-3."""
+    tr, img, ref_img = cases.run_cut_steps(DEV, HipOps(torch.device(DEV)), True, amp=False, S=S, B=B, nsteps=1, tol0=1e-3)
+    np.testing.assert_allclose(img.numpy(), ref_img.numpy(), rtol=1e-3, atol=1e-3)
+
+
 def test_cut_train_step_bf16_vs_oracle():
     """bf16 throughput mode (fp32 accumulation): same step, tolerance widened to bf16's 8-bit mantissa."""
     tr, img, ref_img = cases.run_cut_steps(DEV, HipOps(torch.device(DEV)), True, amp=True, S=64, B=2, nsteps=1, tol0=4e-2, ptol=4.5e-4)
