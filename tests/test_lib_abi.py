@@ -56,6 +56,16 @@ def test_argument_validation_messages():
     assert lib.gan_adam_step(None, 0, None, None, 0, C.c_float(1e-3), C.c_float(0.5), C.c_float(0.999), C.c_float(1e-8), C.c_float(0), C.c_float(1),
                              C.c_float(0), None, None, 0, None, None, None) < 0
     assert lib.gan_pack_weight_batch(None, 0, 0, None) < 0 and b"pack_weight_batch" in lib.gan_last_error()
+    # operand tensors beyond the kernels' 32-bit byte offsets are refused, not truncated (a batch of 600 images of a 130 x 130 x 256 map)
+    big = _lib.GanConvDesc()
+    big.dtype, big.B, big.Ho, big.Wo, big.Cin, big.ntaps, big.Nw, big.Nst = _lib.BF16, 600, 128, 128, 256, 9, 256, 256
+    big.in_Hp = big.in_Wp = 130
+    big.in_sy = big.in_sx = big.out_sy = big.out_sx = 1
+    big.out_Hp = big.out_Wp = 128
+    big.out_C = 256
+    big.in_ = big.w = big.out = big.tapoff = 1 << 20            # aligned, never dereferenced: validation fails first
+    assert lib.gan_conv_igemm(C.byref(big), None) < 0 and b"4 GiB" in lib.gan_last_error()
+    assert lib.gan_conv_patch_ok(C.byref(big)) == 0
 
 
 def test_library_shares_the_hip_runtime_torch_uses():
