@@ -476,14 +476,67 @@ extern "C" int gan_conv_wgrad(const gan_wgrad_desc* d, void* stream) {
   return 0;
 }
 
+// Few outputs, many slabs (the 7x7 C = 3 layers: 6 k quads x 256 slabs; the stride-2 layers' 100 slabs): one thread per quad walked its slabs
+// one dependent 16-byte load after the other -- 64 us for 26 MB at the END of the backward, where the optimiser waits for it (and 208 us
+// beside other work).  Here G = 2, 4 ... 32 neighbouring lanes share a quad: lane l adds slabs l, l + G, ... in ascending order, the lanes are
+// combined by an xor butterfly (a fixed association: deterministic, the same on every run).
+template <int G>
+__global__ __launch_bounds__(256) void wgrad_reduce_coop_kernel(const float* __restrict__ part, int nsplit, int N, int ntaps, int Cx, int N_real,
+                                                               int C_real, int swap, int I2, int KK, const int32_t* __restrict__ khw,
+                                                               float* __restrict__ grad, int accumulate) {
+  const int c4n = Cx >> 2;
+  const int64_t total = (int64_t)N_real * ntaps * c4n;
+  const int64_t slab = (int64_t)N * ntaps * Cx;
+  const int l = threadIdx.x & (G - 1);
+  // the G lanes of a group (aligned, inside one wave) share i: they enter and leave the loop together, which the shuffles below need
+  for (int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G; i < total; i += (int64_t)gridDim.x * blockDim.x / G) {
+    const int c = (int)(i % c4n) * 4;
+    const int t = (int)((i / c4n) % ntaps);
+    const int n = (int)(i / ((int64_t)c4n * ntaps));
+    const int k = khw[t];
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    if (k >= 0 && c < C_real) {
+      const float* p = part + ((int64_t)n * ntaps + t) * Cx + c;
+      for (int sp = l; sp < nsplit; sp += G) s += *reinterpret_cast<const f32x4_t*>(p + sp * slab);
+    }
+#pragma unroll
+    for (int o = G / 2; o >= 1; o >>= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += __shfl_xor(s[e], o, 64);
+    }
+    if (l == 0 && k >= 0 && c < C_real) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (c + e >= C_real) break;
+        const int64_t o = swap ? ((int64_t)(c + e) * I2 + n) * KK + k : ((int64_t)n * I2 + c + e) * KK + k;
+        grad[o] = accumulate ? grad[o] + s[e] : s[e];
+      }
+    }
+  }
+}
+
 extern "C" int gan_wgrad_reduce(const float* part, int nsplit, int N, int ntaps, int Cx, int N_real, int C_real, int swap, int I2,
                                 int KK, const int32_t* khw, float* grad, int accumulate, void* stream) {
   GAN_CHECK(part && khw && grad && nsplit > 0 && N_real <= N && C_real <= Cx, "wgrad_reduce: bad arguments");
   GAN_CHECK(Cx % 4 == 0 && ((uintptr_t)part % 16) == 0, "wgrad_reduce: Cx must be a multiple of 4 and part 16-byte aligned");
   const int64_t total = (int64_t)N_real * ntaps * (Cx / 4);
-  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, part, nsplit, N, ntaps, Cx, N_real, C_real, swap,
-                     I2, KK, khw, grad, accumulate);
+  // lanes per output quad: enough threads to cover the load latency (~64 k), at most one lane per 4 slabs
+  static const int coop_env = [] { const char* e = getenv("GAN_WGRAD_REDUCE_COOP"); return e ? atoi(e) : -1; }();    // A/B: 0 = off, else forced G
+  int G = 1;
+  while (G < 32 && total * G < 65536 && G * 8 <= nsplit) G *= 2;
+  if (coop_env >= 0) G = coop_env <= 1 ? 1 : coop_env >= 32 ? 32 : coop_env >= 16 ? 16 : coop_env >= 8 ? 8 : coop_env >= 4 ? 4 : 2;
+  const int64_t thr = total * G;
+  const int grid = (int)((thr + 255) / 256 < 8192 ? (thr + 255) / 256 : 8192);
+#define GAN_REDUCE_COOP(GG) hipLaunchKernelGGL(wgrad_reduce_coop_kernel<GG>, dim3(grid), dim3(256), 0, (hipStream_t)stream, part, nsplit, N, ntaps, Cx, \
+                                               N_real, C_real, swap, I2, KK, khw, grad, accumulate)
+  if (G == 1) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, part, nsplit, N, ntaps, Cx, N_real, C_real, swap,
+                                 I2, KK, khw, grad, accumulate);
+  else if (G == 2) GAN_REDUCE_COOP(2);
+  else if (G == 4) GAN_REDUCE_COOP(4);
+  else if (G == 8) GAN_REDUCE_COOP(8);
+  else if (G == 16) GAN_REDUCE_COOP(16);
+  else GAN_REDUCE_COOP(32);
+#undef GAN_REDUCE_COOP
   GAN_LAUNCH_CHECK();
   return 0;
 }
