@@ -339,6 +339,9 @@ extern "C" int gan_conv_igemm(const gan_conv_desc* d, void* stream) {
     GAN_DISPATCH_DTYPE(d->dtype, return launch_conv<T, 2, 2, 2>(a, s);)
   } else {
     GAN_CHECK(d->Nw == 16, "conv: Nw=%d must be 16 or a multiple of 64", d->Nw);
+    // few rows and a long reduction (the discriminator's 512 -> 1 4x4 convolution: 113 tiles of 256 rows x 128 K-steps -- 85 us for 31 MB of input on
+    // less than half of the CUs): 64-row tiles, one wave per block, four times the blocks
+    if ((M + 255) / 256 < 256) { GAN_DISPATCH_DTYPE(d->dtype, return launch_conv<T, 1, 1, 1>(a, s);) }
     GAN_DISPATCH_DTYPE(d->dtype, return launch_conv<T, 4, 1, 1>(a, s);)
   }
 }
